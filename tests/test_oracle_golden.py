@@ -1,0 +1,285 @@
+"""Pin the CPU oracle (oracle/ref.py, oracle/bucket_ref.c) against the golden vectors generated
+from the reference's PyTorch sibling (oracle/gen_golden.py) and against the truth tables /
+properties the reference's own tests hold.  CPU only."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+from oracle import ref
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+# ------------------------------------------------------------------ masks
+def test_mask_goldens_bit_exact():
+    g = load('mask_self.npz')
+    for tag, B, L in [('t', 4, 8), ('doc', 2, 8)]:
+        vl = g[tag + '_vl']
+        for layout in ['NT', 'TN']:
+            shape = (B, L, 5) if layout == 'NT' else (L, B, 5)
+            for attn_type in ['full', 'causal']:
+                m = ref.gen_self_attn_mask(np.zeros(shape), vl, attn_type=attn_type, layout=layout)
+                assert m.dtype == np.bool_
+                assert_array_equal(m, g['{}_{}_{}'.format(tag, attn_type, layout)])
+            m = ref.gen_self_attn_mask(np.zeros(shape), None, attn_type='causal', layout=layout)
+            assert_array_equal(m, g['{}_causal_novl_{}'.format(tag, layout)])
+
+
+def test_mask_truth_tables():
+    """Exact expectations of reference tests/test_attention_cell.py:225-269 and the docstring
+    tables attention_cell.py:63-121."""
+    rng = np.random.default_rng(0)
+    B, Lq, Lm = 4, 8, 6
+    vl = rng.integers(1, Lq + 1, size=B)
+    mvl = rng.integers(1, Lm + 1, size=B)
+    full = ref.gen_self_attn_mask((B, Lq, 5), vl, attn_type='full')
+    causal = ref.gen_self_attn_mask((B, Lq, 5), vl, attn_type='causal')
+    mem = ref.gen_mem_attn_mask((B, Lm, 5), mvl, (B, Lq, 5), vl)
+    for b in range(B):
+        for i in range(Lq):
+            if i < vl[b]:
+                assert full[b, i, :vl[b]].all() and not full[b, i, vl[b]:].any()
+                assert causal[b, i, :i + 1].all() and not causal[b, i, i + 1:].any()
+                assert mem[b, i, :mvl[b]].all() and not mem[b, i, mvl[b]:].any()
+            else:
+                assert not full[b, i].any() and not causal[b, i].any() and not mem[b, i].any()
+    # docstring example, vl = [8, 6], second sample causal row 'you' = 1 1 1 1 1 1 0 0
+    c = ref.gen_self_attn_mask((2, 8, 1), np.array([8, 6]), attn_type='causal')
+    assert_array_equal(c[1, 5], [1, 1, 1, 1, 1, 1, 0, 0])
+    assert_array_equal(c[1, 6], [0] * 8)
+    # no data_valid_length: every query row sees the memory mask
+    mem2 = ref.gen_mem_attn_mask((B, Lm, 5), mvl, (B, Lq, 5), None)
+    for b in range(B):
+        assert mem2[b, :, :mvl[b]].all() and not mem2[b, :, mvl[b]:].any()
+    # TN == NT
+    assert_array_equal(ref.gen_self_attn_mask((Lq, B, 5), vl, layout='TN'), full)
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize('H', [1, 2, 3])
+def test_attention_goldens(H):
+    g = load('attn_h{}.npz'.format(H))
+    q, k, v = g['q'].astype(np.float64), g['k'].astype(np.float64), g['v'].astype(np.float64)
+    mask = g['mask']
+    for scaled in [True, False]:
+        for ename in ['none', 'share', 'head']:
+            e = None if ename == 'none' else g['e_' + ename].astype(np.float64)
+            key = 's{}_{}'.format(int(scaled), ename)
+            for layout, perm, back in [('NKT', None, None), ('NTK', (0, 2, 1, 3), None),
+                                       ('TNK', (2, 0, 1, 3), (1, 0, 2))]:
+                qq, kk, vv = [x if perm is None else np.transpose(x, perm) for x in (q, k, v)]
+                ctx, (scores, w) = ref.multi_head_dot_attn(qq, kk, vv, mask, e, scaled=scaled,
+                                                           query_head_units=q.shape[-1],
+                                                           layout=layout)
+                if back is not None:
+                    ctx = np.transpose(ctx, back)
+                assert_allclose(ctx, g[key + '_ctx'], rtol=1e-10, atol=1e-12)
+                assert_allclose(scores, g[key + '_scores'], rtol=1e-10, atol=1e-12)
+                assert_allclose(w, g[key + '_w'], rtol=1e-10, atol=1e-12)
+                # reference test property: masked weights are exactly zero
+                for h in range(H):
+                    assert (w[:, h][mask == 0] == 0).all()
+                # torch-sibling property: row sums in {0, 1}
+                rs = w.sum(-1)
+                full_masked = (mask.sum(-1) == 0)[:, None, :].repeat(H, 1)
+                assert_allclose(rs[~full_masked], 1.0, atol=1e-12)
+                assert (rs[full_masked] == 0).all()
+    ctx, (_, w) = ref.multi_head_dot_attn(q, k, v, None, None, scaled=True,
+                                          query_head_units=q.shape[-1])
+    assert_allclose(ctx, g['nomask_ctx'], rtol=1e-10, atol=1e-12)
+    assert_allclose(w, g['nomask_w'], rtol=1e-10, atol=1e-12)
+
+
+def test_attention_errors_and_normalized():
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((2, 2, 4, 8))
+    with pytest.raises(NotImplementedError):
+        ref.multi_head_dot_attn(q, q, q, scaled=True, query_head_units=None)
+    with pytest.raises(NotImplementedError):
+        ref.multi_head_dot_attn(q, q, q, scaled=False, layout='KNT')
+    # normalized: x / (||x|| + eps)  (op.py:306) -- score of a vector with itself is < 1
+    _, (scores, _) = ref.multi_head_dot_attn(q, q, q, scaled=False, normalized=True, eps=1e-6)
+    n = np.linalg.norm(q, axis=-1)
+    expect = (n / (n + 1e-6)) ** 2
+    assert_allclose(np.diagonal(scores, axis1=-2, axis2=-1), expect, rtol=1e-12)
+
+
+# ------------------------------------------------------------------ FFN / layer / stacks
+def _params(g, prefix):
+    n = len(prefix)
+    return {k[n:]: g[k].astype(np.float64) for k in g.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize('name,kw', [
+    ('postnorm_relu', dict(activation_name='relu', layer_norm_eps=1e-5)),
+    ('postnorm_gelu', dict(activation_name='gelu', layer_norm_eps=1e-12)),
+    ('prenorm_gelu', dict(activation_name='gelu', pre_norm=True, layer_norm_eps=1e-5)),
+    ('gated_gelu_tanh', dict(activation_name='gelu(tanh)', use_gated_activation=True,
+                             layer_norm_eps=1e-5)),
+])
+def test_ffn_goldens(name, kw):
+    g = load('ffn.npz')
+    y = ref.positionwise_ffn(g[name + '_x'].astype(np.float64), _params(g, name + '/'), **kw)
+    assert_allclose(y, g[name + '_y'], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize('name,H,eps,act', [
+    ('enc_tiny_eps1e-12', 2, 1e-12, 'gelu'), ('enc_tiny_eps1e-5', 2, 1e-5, 'gelu'),
+    ('enc_tiny_relu_vl1', 4, 1e-5, 'relu'), ('enc_d64', 2, 1e-12, 'gelu')])
+def test_encoder_layer_and_stack_goldens(name, H, eps, act):
+    g = load(name + '.npz')
+    x = g['x'].astype(np.float64)
+    vl = g['valid_length']
+    layers = [_params(g, 'L0/'), _params(g, 'L1/')]
+    mask = ref.gen_self_attn_mask(x, vl)
+    h, w = ref.transformer_encoder_layer(x, mask, layers[0], H, eps, False, act, 'NT')
+    assert_allclose(h, g['out_L0'], rtol=1e-8, atol=1e-10)
+    assert_allclose(w, g['attn_w_L0'], rtol=1e-8, atol=1e-12)
+    out, _ = ref.bert_transformer(x, vl, layers, H, eps, act, 'NT')
+    assert_allclose(out, g['out_seqmask'], rtol=1e-8, atol=1e-10)
+    out_r, _ = ref.roberta_encoder(x, vl, layers, H, eps, act, 'NT')
+    assert_allclose(out_r, g['out_L1'], rtol=1e-8, atol=1e-10)
+    # NT vs TN (reference tests/test_models_bert.py:51-54, 1e-4; exact here up to rounding)
+    out_tn, _ = ref.bert_transformer(np.swapaxes(x, 0, 1), vl, layers, H, eps, act, 'TN')
+    assert_allclose(np.swapaxes(out_tn, 0, 1), out, rtol=1e-10, atol=1e-12)
+    # outputs beyond valid_length are exactly 0 (tests/test_models_albert.py:65-84)
+    for b, n in enumerate(vl):
+        assert (out[b, n:] == 0).all()
+    # output_all_encodings masks every layer and feeds the masked tensor on (bert.py:300-304)
+    allenc, _ = ref.bert_transformer(x, vl, layers, H, eps, act, 'NT', output_all_encodings=True)
+    assert len(allenc) == 2
+    assert_allclose(allenc[-1], out, rtol=1e-8, atol=1e-10)
+
+
+def test_padding_invariance():
+    """Appending padding does not change valid outputs (tests/test_models_albert.py:65-84)."""
+    rng = np.random.default_rng(5)
+    U, F, H, B, L = 32, 64, 4, 3, 10
+    layers = [ref.make_encoder_layer_params(rng, U, F, np.float64) for _ in range(2)]
+    x = rng.standard_normal((B, L, U))
+    vl = np.array([10, 4, 7])
+    out, _ = ref.bert_transformer(x, vl, layers, H)
+    xp = np.concatenate([x, rng.standard_normal((B, 6, U))], axis=1)
+    outp, _ = ref.bert_transformer(xp, vl, layers, H)
+    assert_allclose(outp[:, :L], out, rtol=1e-9, atol=1e-11)
+    assert (outp[:, L:] == 0).all()
+
+
+def test_pre_norm_residual_follows_mx_text():
+    """MX adds the *normalised* input (models/transformer.py:259-268); torch sibling the raw."""
+    rng = np.random.default_rng(6)
+    U, F, H = 16, 32, 2
+    p = ref.make_encoder_layer_params(rng, U, F, np.float64)
+    x = rng.standard_normal((2, 5, U))
+    mask = ref.gen_self_attn_mask(x, np.array([5, 3]))
+    a, _ = ref.transformer_encoder_layer(x, mask, p, H, 1e-5, True, 'relu', 'NT', True)
+    b, _ = ref.transformer_encoder_layer(x, mask, p, H, 1e-5, True, 'relu', 'NT', False)
+    assert not np.allclose(a, b)
+
+
+# ------------------------------------------------------------------ T5 pieces
+def _c_bucket(rel, bidirectional, num_buckets, max_distance):
+    so = os.path.join(os.path.dirname(G), '..', 'oracle', '_build', 'libgnlp_oracle.so')
+    so = os.path.abspath(so)
+    if not os.path.exists(so):
+        pytest.skip('oracle C library not built (run __graft_entry__.build())')
+    lib = ctypes.CDLL(so)
+    rel = np.ascontiguousarray(rel, dtype=np.int32)
+    out = np.empty_like(rel)
+    lib.oracle_relative_position_bucket(
+        rel.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+        ctypes.c_int64(rel.size), int(bidirectional), int(num_buckets), int(max_distance))
+    return out
+
+
+@pytest.mark.parametrize('bidirectional', [True, False])
+@pytest.mark.parametrize('num_buckets,max_distance', [(32, 128), (64, 256), (32, 256)])
+def test_bucket_numpy_vs_c_vs_hf(bidirectional, num_buckets, max_distance):
+    rel = np.concatenate([np.arange(-10000, 10001), np.arange(-10, 11)]).astype(np.int32)
+    a = ref.relative_position_bucket(rel, bidirectional, num_buckets, max_distance)
+    b = _c_bucket(rel, bidirectional, num_buckets, max_distance)
+    assert a.dtype == np.int32
+    assert_array_equal(a, b)
+    # independent pin: HuggingFace T5's bucket function implements the same mesh-tf algorithm
+    try:
+        import torch
+        from transformers.models.t5.modeling_t5 import T5Attention
+    except Exception:
+        return
+    c = T5Attention._relative_position_bucket(torch.from_numpy(rel.astype(np.int64)),
+                                              bidirectional=bidirectional,
+                                              num_buckets=num_buckets,
+                                              max_distance=max_distance).numpy()
+    assert_array_equal(a, c.astype(np.int32))
+
+
+def test_bucket_properties():
+    """reference tests/test_layers.py:200-224."""
+    for nb, md in [(32, 128), (64, 256)]:
+        rel = np.arange(-1000, 1001).astype(np.int32)
+        b = ref.relative_position_bucket(rel, True, nb, md)
+        assert (b[rel > 0] >= nb // 2).all()           # :220-221
+        assert (b[rel <= 0] < nb // 2).all()
+        assert (b[rel >= md] == nb - 1).all()          # saturation
+        assert (b[rel <= -md] == nb // 2 - 1).all()
+        assert b.min() == 0 and b.max() == nb - 1
+    g = ref.gen_rel_position((2, 7, 3))
+    assert g.dtype == np.int32 and g.shape == (7, 7)
+    assert g[2, 5] == 3 and g[5, 2] == -3              # mem_j - query_i
+    w = np.random.default_rng(0).standard_normal((32, 4))
+    s = ref.rel_attention_score_t5(w, g)
+    assert s.shape == (4, 7, 7)
+    assert_array_equal(s[:, 2, 5], w[ref.relative_position_bucket(np.int32(3))])
+
+
+def test_t5_block_prefix_consistency():
+    """tests/test_models_t5.py: shapes + NT/TN agreement for the T5 encoder restatement."""
+    rng = np.random.default_rng(9)
+    d_model, d_kv, d_ff, H, B, L = 32, 8, 64, 4, 3, 12
+    for act in ['relu', 'gated-gelu']:
+        layers = [ref.make_t5_block_params(rng, d_model, d_kv, d_ff, H, act != 'relu', np.float64)
+                  for _ in range(2)]
+        relw = rng.standard_normal((32, H))
+        fin = {'gamma': np.ones(d_model), 'beta': np.zeros(d_model)}
+        x = rng.standard_normal((B, L, d_model))
+        vl = np.array([12, 5, 1])
+        y = ref.t5_encoder(x, vl, relw, layers, fin, H, activation_name=act)
+        y_tn = ref.t5_encoder(np.swapaxes(x, 0, 1), vl, relw, layers, fin, H, activation_name=act,
+                              layout='TN')
+        assert_allclose(np.swapaxes(y_tn, 0, 1), y, rtol=1e-10, atol=1e-12)
+        # padding invariance on valid tokens
+        xp = np.concatenate([x, rng.standard_normal((B, 4, d_model))], axis=1)
+        yp = ref.t5_encoder(xp, vl, relw, layers, fin, H, activation_name=act)
+        for b, n in enumerate(vl):
+            assert_allclose(yp[b, :n], y[b, :n], rtol=1e-9, atol=1e-11)
+
+
+def test_softmax_and_norm_semantics():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 3, 4, 5))
+    m = rng.integers(0, 2, size=(2, 1, 4, 5)).astype(bool)
+    m[0, 0, 1] = False
+    w = ref.masked_softmax(x, m, temperature=2.0)
+    neg = np.where(m, x, -1e18) / 2.0     # utils/tvm_utils.py:59-75 restatement
+    e = np.exp(neg - neg.max(-1, keepdims=True))
+    assert_allclose(w, e / e.sum(-1, keepdims=True) * m, rtol=1e-12, atol=1e-15)
+    assert (w[0, :, 1] == 0).all()
+    ls = ref.masked_logsoftmax(x, m)
+    assert np.isneginf(ls[~np.broadcast_to(m, x.shape)]).all()
+    g = rng.standard_normal(5)
+    b = rng.standard_normal(5)
+    y = ref.rms_norm(x, g, b, 1e-6)
+    assert_allclose(y, x / np.sqrt((x ** 2).mean(-1, keepdims=True) + 1e-6) * g + b, rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        ref.activation(x, 'swish')
+    with pytest.raises(ValueError):
+        ref.gelu(x, 'foo')
+    with pytest.raises(NotImplementedError):
+        ref.norm(x, {}, 'group_norm')
