@@ -1,0 +1,715 @@
+// C ABI of the MI355X-native encoder forward path (declared in include/gluonnlp_amd.h).
+// Host side only: argument checking, kernel selection, the per-block launch sequences.
+// No allocation, no synchronisation, no global state: everything is enqueued on the caller's
+// HIP stream into caller-owned buffers.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace gnlp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GNLP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return GNLP_OK;
+}
+
+inline bool dtype_ok(int d) { return d == GNLP_F32 || d == GNLP_BF16; }
+inline bool vl_ok(int d) { return d == GNLP_I32 || d == GNLP_I64; }
+inline size_t esize(int d) { return d == GNLP_BF16 ? 2 : 4; }
+inline hipStream_t S(gnlp_stream_t s) { return (hipStream_t)s; }
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+#define REQUIRE(cond, ...) \
+  do { if (!(cond)) return fail(GNLP_ERR_ARG, __VA_ARGS__); } while (0)
+
+// Host part of relative_position_bucket (op.py:261-286): find, with the reference's own float32
+// formulation (libm logf), the integer distances at which the bucket index increments.
+int bucket_value(int n, int max_exact, int nb, float denom) {
+  float rr = logf((float)n / (float)max_exact) / denom * (float)(nb - max_exact);
+  return max_exact + (int)rr;
+}
+
+int build_bucket_table(BucketTable *tb, int bidirectional, int num_buckets, int max_distance) {
+  REQUIRE(num_buckets >= 2 && num_buckets <= 256, "num_buckets=%d out of range [2, 256]", num_buckets);
+  REQUIRE(!bidirectional || num_buckets % 2 == 0,
+          "When bidirectional is True, the number of buckets must be divisible by 2.");
+  int nb = bidirectional ? num_buckets / 2 : num_buckets;
+  const int max_exact = nb / 2;
+  REQUIRE(max_exact >= 1, "num_buckets too small");
+  REQUIRE(max_distance > max_exact, "max_distance=%d must exceed max_exact=%d", max_distance, max_exact);
+  tb->bidirectional = bidirectional ? 1 : 0;
+  tb->half = nb;
+  tb->max_exact = max_exact;
+  tb->n_thr = nb - 1 - max_exact;
+  const float denom = (float)log((double)max_distance / (double)max_exact);
+  const int HI = 1 << 30;
+  for (int q = 0; q < tb->n_thr; ++q) {
+    const int target = max_exact + q + 1;
+    // smallest n >= max_exact with bucket_value(n) >= target (monotone in n)
+    if (bucket_value(HI, max_exact, nb, denom) < target) { tb->thr[q] = 0x7fffffff; continue; }
+    int lo = max_exact, hi = HI;  // invariant: value(lo) < target <= value(hi)
+    if (bucket_value(lo, max_exact, nb, denom) >= target) { tb->thr[q] = lo; continue; }
+    while (hi - lo > 1) {
+      const int mid = lo + (hi - lo) / 2;
+      if (bucket_value(mid, max_exact, nb, denom) >= target) hi = mid; else lo = mid;
+    }
+    tb->thr[q] = hi;
+  }
+  return GNLP_OK;
+}
+
+// ---- dense dispatcher --------------------------------------------------------------------------
+int dense_impl(void *out, const void *x, const void *w, const void *bias, const void *other,
+               int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
+               int64_t ldo, int64_t ldother, hipStream_t s) {
+  if (M == 0 || N == 0) return GNLP_OK;
+  const bool bias_al = (!bias || ((uintptr_t)bias % 16 == 0)) && mfma_dense_act_fused(act);
+  if (dtype == GNLP_BF16 && bias_al &&
+      mfma_bf16_dense_supported(M, N, K, ldx, ldo, ldother, x, w, out, other)) {
+    launch_mfma_bf16_dense(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
+  } else if (dtype == GNLP_F32 && bias_al &&
+             mfma_f32_dense_supported(M, N, K, ldx, ldo, ldother, x, w, out, other)) {
+    launch_mfma_f32_dense(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
+  } else {
+    GenericGemm g;
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.Bm = w; g.C = out; g.bias = bias; g.other = other;
+    g.M = M; g.N = N; g.K = K; g.nb0 = 1; g.nb1 = 1;
+    g.sAm = ldx; g.sBn = K; g.sCm = ldo; g.sOm = ldother; g.sOn = 1;
+    g.trans_b = 1; g.act = act; g.combine = combine;
+    g.in_dtype = g.out_dtype = g.other_dtype = dtype;
+    g.alpha = 1.0f;
+    launch_generic_gemm(g, s);
+  }
+  return check_launch("gnlp_dense");
+}
+
+// ---- attention dispatcher ----------------------------------------------------------------------
+size_t attn_ws_bytes(const gnlp_attn_desc *d, int dtype, bool want_scores, bool want_weights,
+                     bool fused) {
+  if (fused) return 0;
+  if (want_scores && want_weights) return 0;
+  return align256((size_t)d->B * d->H * d->Lq * d->Lm * esize(dtype));
+}
+
+bool can_fuse(const gnlp_attn_desc *d, int dtype, const void *q, const void *k, const void *v,
+              void *ctx, const void *edge, const int64_t *es, FusedAttn *fa) {
+  if (dtype != GNLP_BF16) return false;
+  memset(fa, 0, sizeof(*fa));
+  fa->q = q; fa->k = k; fa->v = v; fa->o = ctx;
+  fa->B = d->B; fa->H = d->H; fa->Lq = d->Lq; fa->Lm = d->Lm;
+  for (int i = 0; i < 3; ++i) {
+    fa->qs[i] = d->q_stride[i]; fa->ks[i] = d->k_stride[i];
+    fa->vs[i] = d->v_stride[i]; fa->os[i] = d->o_stride[i];
+  }
+  fa->bias = edge;
+  if (edge) for (int i = 0; i < 4; ++i) fa->bs[i] = es[i];
+  return fused_attn_supported(*fa, d->dk, d->dv);
+}
+
+int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, const void *k,
+              const void *v, const gnlp_attn_desc *d, int dtype, const uint8_t *mask,
+              const int64_t *ms, const void *vl, int vl_dtype, const void *edge, const int64_t *es,
+              float temperature, void *ws, size_t ws_bytes, hipStream_t s) {
+  if (d->B == 0 || d->H == 0 || d->Lq == 0) return GNLP_OK;
+  const float inv_t = temperature > 0.0f ? 1.0f / temperature : 1.0f;
+  FusedAttn fa;
+  if (!scores_out && !weights_out && can_fuse(d, dtype, q, k, v, ctx, edge, es, &fa)) {
+    fa.mask = mask;
+    if (mask) { fa.ms[0] = ms[0]; fa.ms[1] = ms[1]; fa.ms[2] = ms[2]; }
+    fa.vl = vl; fa.vl_dtype = vl_dtype;
+    fa.bias = edge;
+    if (edge) for (int i = 0; i < 4; ++i) fa.bs[i] = es[i];
+    fa.inv_temperature = inv_t;
+    launch_fused_attn_bf16(fa, s);
+    return check_launch("fused attention");
+  }
+  // ---- unfused path: scores -> masked softmax -> context (attention_cell.py:452-463) ----
+  const size_t need = attn_ws_bytes(d, dtype, scores_out != nullptr, weights_out != nullptr, false);
+  REQUIRE(ws_bytes >= need && (need == 0 || ws != nullptr),
+          "attention workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+  void *scores = scores_out ? scores_out : (weights_out ? ws : ws);
+  void *weights = weights_out ? weights_out : ws;  // in place over `scores` when both share ws
+  if (!scores_out && !weights_out) { scores = ws; weights = ws; }
+  const int64_t LL = d->Lq * d->Lm;
+  GenericGemm g;
+  memset(&g, 0, sizeof(g));
+  g.A = q; g.Bm = k; g.C = scores; g.other = edge;
+  g.M = d->Lq; g.N = d->Lm; g.K = d->dk; g.nb0 = d->B; g.nb1 = d->H;
+  g.sAb0 = d->q_stride[0]; g.sAb1 = d->q_stride[1]; g.sAm = d->q_stride[2];
+  g.sBb0 = d->k_stride[0]; g.sBb1 = d->k_stride[1]; g.sBn = d->k_stride[2];
+  g.sCb0 = d->H * LL; g.sCb1 = LL; g.sCm = d->Lm;
+  if (edge) { g.sOb0 = es[0]; g.sOb1 = es[1]; g.sOm = es[2]; g.sOn = es[3]; }
+  g.trans_b = 1; g.act = GNLP_ACT_IDENTITY; g.combine = GNLP_COMBINE_ADD;
+  g.in_dtype = g.out_dtype = g.other_dtype = dtype;
+  g.alpha = 1.0f;
+  launch_generic_gemm(g, s);
+  const int64_t shape[4] = {d->B, d->H, d->Lq, d->Lm};
+  int64_t mstr[4] = {0, 0, 0, 0};
+  if (mask) { mstr[0] = ms[0]; mstr[1] = 0; mstr[2] = ms[1]; mstr[3] = ms[2]; }
+  launch_masked_softmax(weights, scores, dtype, mask, mstr, shape, mask ? nullptr : vl, vl_dtype,
+                        inv_t, 0, s);
+  memset(&g, 0, sizeof(g));
+  g.A = weights; g.Bm = v; g.C = ctx;
+  g.M = d->Lq; g.N = d->dv; g.K = d->Lm; g.nb0 = d->B; g.nb1 = d->H;
+  g.sAb0 = d->H * LL; g.sAb1 = LL; g.sAm = d->Lm;
+  g.sBb0 = d->v_stride[0]; g.sBb1 = d->v_stride[1]; g.sBn = d->v_stride[2];
+  g.sCb0 = d->o_stride[0]; g.sCb1 = d->o_stride[1]; g.sCm = d->o_stride[2];
+  g.trans_b = 0; g.act = GNLP_ACT_IDENTITY; g.combine = GNLP_COMBINE_ADD;
+  g.in_dtype = g.out_dtype = g.other_dtype = dtype;
+  g.alpha = 1.0f;
+  launch_generic_gemm(g, s);
+  return check_launch("unfused attention");
+}
+
+// ---- FFN ---------------------------------------------------------------------------------------
+struct FfnWs { size_t normed, hidden, gate, total; };
+FfnWs ffn_ws(const gnlp_ffn_cfg *c, int64_t rows) {
+  FfnWs w;
+  const size_t e = esize(c->dtype);
+  size_t off = 0;
+  w.normed = off; off += c->pre_norm ? align256((size_t)rows * c->units * e) : 0;
+  w.hidden = off; off += align256((size_t)rows * c->hidden * e);
+  w.gate = off; off += c->gated ? align256((size_t)rows * c->hidden * e) : 0;
+  // post-norm needs the pre-LN sum; it is written over `normed`-less layouts into its own slot
+  w.total = off + (c->pre_norm ? 0 : align256((size_t)rows * c->units * e));
+  return w;
+}
+
+int ffn_impl(void *out, const void *x, const gnlp_ffn_params *p, const gnlp_ffn_cfg *c,
+             int64_t rows, const void *vl, int vl_dtype, int64_t B, int64_t L, int time_major,
+             void *ws, size_t ws_bytes, hipStream_t s) {
+  const FfnWs w = ffn_ws(c, rows);
+  REQUIRE(ws && ws_bytes >= w.total, "ffn workspace too small: need %zu bytes, got %zu", w.total,
+          ws_bytes);
+  char *base = (char *)ws;
+  const int64_t U = c->units, F = c->hidden;
+  const void *in = x;
+  int rc;
+  if (c->pre_norm) {  // layers.py:634-635
+    launch_norm(base + w.normed, x, nullptr, p->ln_g, p->ln_b, c->dtype, c->norm_kind, c->ln_eps,
+                rows, U, nullptr, 0, 0, 0, 0, s);
+    in = base + w.normed;
+  }
+  void *hidden = base + w.hidden;
+  if (c->gated) {     // layers.py:636-638: act(gated_ffn_1(x)) * ffn_1(x)
+    void *gate = base + w.gate;
+    rc = dense_impl(gate, in, p->gate_w, p->gate_b, nullptr, 0, c->act, c->dtype, rows, F, U, U, F,
+                    0, s);
+    if (rc) return rc;
+    rc = dense_impl(hidden, in, p->ffn1_w, p->ffn1_b, gate, GNLP_COMBINE_MUL, GNLP_ACT_IDENTITY,
+                    c->dtype, rows, F, U, U, F, F, s);
+    if (rc) return rc;
+  } else {            // layers.py:640
+    rc = dense_impl(hidden, in, p->ffn1_w, p->ffn1_b, nullptr, 0, c->act, c->dtype, rows, F, U, U,
+                    F, 0, s);
+    if (rc) return rc;
+  }
+  if (c->pre_norm) {  // out = ffn_2(h) + residual(x)   layers.py:642-644
+    rc = dense_impl(out, hidden, p->ffn2_w, p->ffn2_b, x, GNLP_COMBINE_ADD, GNLP_ACT_IDENTITY,
+                    c->dtype, rows, U, F, F, U, U, s);
+    if (rc) return rc;
+    if (vl) launch_sequence_mask(out, out, vl, vl_dtype, c->dtype, B, L, U, time_major, s);
+  } else {            // out = norm(ffn_2(h) + x)       layers.py:642-646
+    void *sum = base + w.total - align256((size_t)rows * U * esize(c->dtype));
+    rc = dense_impl(sum, hidden, p->ffn2_w, p->ffn2_b, x, GNLP_COMBINE_ADD, GNLP_ACT_IDENTITY,
+                    c->dtype, rows, U, F, F, U, U, s);
+    if (rc) return rc;
+    launch_norm(out, sum, nullptr, p->ln_g, p->ln_b, c->dtype, c->norm_kind, c->ln_eps, rows, U,
+                vl, vl_dtype, B, L, time_major, s);
+  }
+  return check_launch("positionwise_ffn");
+}
+
+gnlp_ffn_cfg ffn_cfg_of(const gnlp_encoder_cfg *c) {
+  gnlp_ffn_cfg f;
+  f.units = c->units; f.hidden = c->hidden; f.act = c->act; f.gated = 0;
+  f.norm_kind = GNLP_NORM_LAYER; f.pre_norm = c->pre_norm; f.dtype = c->dtype; f.ln_eps = c->ln_eps;
+  return f;
+}
+
+// ---- encoder layer -----------------------------------------------------------------------------
+struct EncWs { size_t normed, qkv, ctx, sum, x1, attn, ffn, total; };
+EncWs enc_ws(const gnlp_encoder_cfg *c, int64_t B, int64_t L, bool want_weights) {
+  EncWs w;
+  const size_t e = esize(c->dtype);
+  const int64_t M = B * L, U = c->units;
+  size_t off = 0;
+  w.normed = off; off += c->pre_norm ? align256((size_t)M * U * e) : 0;
+  w.qkv = off; off += align256((size_t)M * 3 * U * e);
+  w.ctx = off; off += align256((size_t)M * U * e);
+  w.sum = off; off += align256((size_t)M * U * e);
+  w.x1 = off; off += c->pre_norm ? 0 : align256((size_t)M * U * e);
+  w.attn = off;
+  gnlp_attn_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = B; d.H = c->heads; d.Lq = L; d.Lm = L; d.dk = d.dv = U / (c->heads ? c->heads : 1);
+  const bool fused = !want_weights && c->dtype == GNLP_BF16 && d.dk == 64 && (U % 8 == 0);
+  off += attn_ws_bytes(&d, c->dtype, false, want_weights, fused);
+  w.ffn = off;
+  gnlp_ffn_cfg f = ffn_cfg_of(c);
+  off += ffn_ws(&f, M).total;
+  w.total = off;
+  return w;
+}
+
+int encoder_layer_impl(void *out, const void *x, const gnlp_encoder_layer_params *p,
+                       const gnlp_encoder_cfg *c, int64_t B, int64_t L, const uint8_t *mask,
+                       const void *vl, int vl_dtype, void *attn_w_out, int final_seq_mask,
+                       void *ws, size_t ws_bytes, hipStream_t s) {
+  const int64_t U = c->units, H = c->heads, M = B * L, d = U / H;
+  const EncWs w = enc_ws(c, B, L, attn_w_out != nullptr);
+  REQUIRE(ws && ws_bytes >= w.total, "encoder workspace too small: need %zu bytes, got %zu",
+          w.total, ws_bytes);
+  char *base = (char *)ws;
+  const size_t e = esize(c->dtype);
+  int rc;
+  const void *in = x;
+  if (c->pre_norm) {  // models/transformer.py:259-260 (data is REBOUND to the normalised tensor)
+    launch_norm(base + w.normed, x, nullptr, p->ln_g, p->ln_b, c->dtype, GNLP_NORM_LAYER,
+                c->ln_eps, M, U, nullptr, 0, 0, 0, 0, s);
+    in = base + w.normed;
+  }
+  char *qkv = base + w.qkv;
+  rc = dense_impl(qkv, in, p->qkv_w, p->qkv_b, nullptr, 0, GNLP_ACT_IDENTITY, c->dtype, M, 3 * U, U,
+                  U, 3 * U, 0, s);  // :261
+  if (rc) return rc;
+  gnlp_attn_desc ad;
+  ad.B = B; ad.H = H; ad.Lq = L; ad.Lm = L; ad.dk = d; ad.dv = d;
+  // rows are tokens: NT -> row = b*L + t ; TN -> row = t*B + b   (:262-264 reshape, :207 layout)
+  const int64_t sb = c->time_major ? 1 : L, st = c->time_major ? B : 1;
+  for (int i = 0; i < 1; ++i) {
+    ad.q_stride[0] = ad.k_stride[0] = ad.v_stride[0] = sb * 3 * U;
+    ad.q_stride[1] = ad.k_stride[1] = ad.v_stride[1] = d;
+    ad.q_stride[2] = ad.k_stride[2] = ad.v_stride[2] = st * 3 * U;
+    ad.o_stride[0] = sb * U; ad.o_stride[1] = d; ad.o_stride[2] = st * U;
+  }
+  const int64_t mstr[3] = {L * L, L, 1};
+  rc = attn_impl(base + w.ctx, nullptr, attn_w_out, qkv, qkv + (size_t)U * e,
+                 qkv + (size_t)2 * U * e, &ad, c->dtype, mask, mstr, vl, vl_dtype, nullptr, nullptr,
+                 sqrtf((float)d), base + w.attn, w.ffn - w.attn, s);  // :265, scaled=True :213
+  if (rc) return rc;
+  // :266-268  out = attention_proj(ctx) + data   (data = normalised input when pre_norm)
+  rc = dense_impl(base + w.sum, base + w.ctx, p->proj_w, p->proj_b, in, GNLP_COMBINE_ADD,
+                  GNLP_ACT_IDENTITY, c->dtype, M, U, U, U, U, U, s);
+  if (rc) return rc;
+  const void *ffn_in = base + w.sum;
+  if (!c->pre_norm) {  // :269-270
+    launch_norm(base + w.x1, base + w.sum, nullptr, p->ln_g, p->ln_b, c->dtype, GNLP_NORM_LAYER,
+                c->ln_eps, M, U, nullptr, 0, 0, 0, 0, s);
+    ffn_in = base + w.x1;
+  }
+  gnlp_ffn_cfg f = ffn_cfg_of(c);
+  return ffn_impl(out, ffn_in, &p->ffn, &f, M, final_seq_mask ? vl : nullptr, vl_dtype, B, L,
+                  c->time_major, base + w.ffn, w.total - w.ffn, s);  // :271
+}
+
+int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
+  REQUIRE(c != nullptr, "cfg is NULL");
+  REQUIRE(dtype_ok(c->dtype), "unsupported dtype %d", c->dtype);
+  REQUIRE(c->units > 0 && c->hidden > 0 && c->heads > 0, "bad units/hidden/heads");
+  REQUIRE(c->units % c->heads == 0, "units must be divisive by the number of heads");
+  REQUIRE(B >= 0 && L >= 0, "negative batch / length");
+  return GNLP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int gnlp_version(void) { return 100; }
+const char *gnlp_last_error(void) { return g_err.c_str(); }
+int gnlp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int gnlp_gen_self_attn_mask(uint8_t *mask, const void *valid_length, int vl_dtype, int64_t B,
+                            int64_t L, int attn_type, gnlp_stream_t stream) {
+  REQUIRE(B >= 0 && L >= 0, "negative shape");
+  REQUIRE(attn_type == GNLP_ATTN_FULL || attn_type == GNLP_ATTN_CAUSAL, "unknown attn_type %d",
+          attn_type);
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
+  REQUIRE(mask || B * L * L == 0, "mask is NULL");
+  launch_self_mask(mask, valid_length, vl_dtype, B, L, attn_type, S(stream));
+  return check_launch("gnlp_gen_self_attn_mask");
+}
+
+int gnlp_gen_mem_attn_mask(uint8_t *mask, const void *mem_valid_length,
+                           const void *data_valid_length, int vl_dtype, int64_t B, int64_t Lq,
+                           int64_t Lm, gnlp_stream_t stream) {
+  REQUIRE(B >= 0 && Lq >= 0 && Lm >= 0, "negative shape");
+  REQUIRE(mem_valid_length != nullptr, "mem_valid_length is NULL");
+  REQUIRE(vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
+  REQUIRE(mask || B * Lq * Lm == 0, "mask is NULL");
+  launch_mem_mask(mask, mem_valid_length, data_valid_length, vl_dtype, B, Lq, Lm, S(stream));
+  return check_launch("gnlp_gen_mem_attn_mask");
+}
+
+int gnlp_sequence_mask(void *out, const void *x, const void *valid_length, int vl_dtype, int dtype,
+                       int64_t B, int64_t L, int64_t C, int time_major, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(valid_length && vl_ok(vl_dtype), "valid_length missing or of bad dtype");
+  REQUIRE(B >= 0 && L >= 0 && C >= 0, "negative shape");
+  REQUIRE((out && x) || B * L * C == 0, "NULL tensor");
+  launch_sequence_mask(out, x, valid_length, vl_dtype, dtype, B, L, C, time_major, S(stream));
+  return check_launch("gnlp_sequence_mask");
+}
+
+int gnlp_masked_softmax(void *out, const void *scores, int dtype, const uint8_t *mask,
+                        const int64_t mask_stride[4], const int64_t shape[4], float temperature,
+                        int log_mode, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(shape != nullptr, "shape is NULL");
+  for (int i = 0; i < 4; ++i) REQUIRE(shape[i] >= 0, "negative shape");
+  REQUIRE(!mask || mask_stride, "mask given without strides");
+  const int64_t n = shape[0] * shape[1] * shape[2] * shape[3];
+  REQUIRE((out && scores) || n == 0, "NULL tensor");
+  REQUIRE(shape[0] * shape[1] * shape[2] < ((int64_t)1 << 33), "too many rows");
+  const float inv_t = temperature > 0.0f ? 1.0f / temperature : 1.0f;
+  int64_t zero[4] = {0, 0, 0, 0};
+  launch_masked_softmax(out, scores, dtype, mask, mask ? mask_stride : zero, shape, nullptr, 0,
+                        inv_t, log_mode, S(stream));
+  return check_launch("gnlp_masked_softmax");
+}
+
+int gnlp_l2_normalize(void *out, const void *x, int dtype, int64_t rows, int64_t d, float eps,
+                      gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(rows >= 0 && d >= 0, "negative shape");
+  REQUIRE((out && x) || rows * d == 0, "NULL tensor");
+  launch_l2_normalize(out, x, dtype, rows, d, eps, S(stream));
+  return check_launch("gnlp_l2_normalize");
+}
+
+int gnlp_activation(void *out, const void *x, int dtype, int64_t n, int act, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(act >= GNLP_ACT_IDENTITY && act <= GNLP_ACT_SOFTSIGN, "act=%d is not supported", act);
+  REQUIRE(n >= 0 && ((out && x) || n == 0), "bad tensor");
+  launch_activation(out, x, dtype, n, act, S(stream));
+  return check_launch("gnlp_activation");
+}
+
+int gnlp_norm(void *out, const void *x, const void *residual, const void *gamma, const void *beta,
+              int dtype, int kind, float eps, int64_t rows, int64_t C, const void *valid_length,
+              int vl_dtype, int64_t B, int64_t L, int time_major, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(kind == GNLP_NORM_LAYER || kind == GNLP_NORM_RMS || kind == GNLP_NORM_NONE,
+          "normalization kind %d is not supported", kind);
+  REQUIRE(rows >= 0 && C >= 0, "negative shape");
+  REQUIRE((out && x && gamma) || rows * C == 0, "NULL tensor");
+  if (valid_length) {
+    REQUIRE(vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
+    REQUIRE(B * L == rows, "valid_length given but B*L (%lld) != rows (%lld)", (long long)(B * L),
+            (long long)rows);
+  }
+  launch_norm(out, x, residual, gamma, beta, dtype, kind, eps, rows, C, valid_length, vl_dtype, B,
+              L, time_major, S(stream));
+  return check_launch("gnlp_norm");
+}
+
+int gnlp_dense(void *out, const void *x, const void *w, const void *bias, const void *other,
+               int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
+               int64_t ldo, int64_t ldother, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative shape");
+  REQUIRE(act >= GNLP_ACT_IDENTITY && act <= GNLP_ACT_SOFTSIGN, "act=%d is not supported", act);
+  REQUIRE(combine == GNLP_COMBINE_ADD || combine == GNLP_COMBINE_MUL, "bad combine %d", combine);
+  REQUIRE(ldx >= K && ldo >= N && (!other || ldother >= N), "leading dimension too small");
+  REQUIRE((out && x && w) || M * N == 0, "NULL tensor");
+  return dense_impl(out, x, w, bias, other, combine, act, dtype, M, N, K, ldx, ldo, ldother,
+                    S(stream));
+}
+
+size_t gnlp_attn_workspace_bytes(const gnlp_attn_desc *d, int dtype, int want_scores,
+                                 int want_weights) {
+  if (!d) return 0;
+  // conservative: the size the unfused path needs (the fused kernel needs none)
+  return attn_ws_bytes(d, dtype, want_scores != 0, want_weights != 0, false);
+}
+
+int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, const void *q,
+                             const void *k, const void *v, const gnlp_attn_desc *d, int dtype,
+                             const uint8_t *mask, const int64_t mask_stride[3],
+                             const void *valid_length, int vl_dtype, const void *edge_scores,
+                             const int64_t edge_stride[4], float temperature, void *workspace,
+                             size_t workspace_bytes, gnlp_stream_t stream) {
+  REQUIRE(d != nullptr, "descriptor is NULL");
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(d->B >= 0 && d->H >= 0 && d->Lq >= 0 && d->Lm >= 0 && d->dk >= 0 && d->dv >= 0,
+          "negative shape");
+  REQUIRE(!mask || mask_stride, "mask given without strides");
+  REQUIRE(!edge_scores || edge_stride, "edge_scores given without strides");
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
+  REQUIRE(d->B * d->H < 65536 * 16, "batch*heads too large");
+  if (d->B * d->H * d->Lq * d->dv == 0) return GNLP_OK;
+  REQUIRE(ctx && q && k && v, "NULL tensor");
+  return attn_impl(ctx, scores_out, weights_out, q, k, v, d, dtype, mask, mask_stride,
+                   valid_length, vl_dtype, edge_scores, edge_stride, temperature, workspace,
+                   workspace_bytes, S(stream));
+}
+
+int gnlp_gen_rel_position(int32_t *out, int64_t L, gnlp_stream_t stream) {
+  REQUIRE(L >= 0 && (out || L == 0), "bad arguments");
+  REQUIRE(L < 46341, "L too large for an (L, L) int32 index grid");
+  launch_rel_position(out, L, S(stream));
+  return check_launch("gnlp_gen_rel_position");
+}
+
+int gnlp_relative_position_bucket(int32_t *out, const int32_t *rel, int64_t n, int bidirectional,
+                                  int num_buckets, int max_distance, gnlp_stream_t stream) {
+  BucketTable tb;
+  int rc = build_bucket_table(&tb, bidirectional, num_buckets, max_distance);
+  if (rc) return rc;
+  REQUIRE(n >= 0 && ((out && rel) || n == 0), "bad arguments");
+  launch_bucket(out, rel, n, tb, S(stream));
+  return check_launch("gnlp_relative_position_bucket");
+}
+
+int gnlp_bucket_embedding(void *out, const void *weight, const int32_t *rel, int dtype, int64_t n,
+                          int64_t units, int bidirectional, int num_buckets, int max_distance,
+                          gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  BucketTable tb;
+  int rc = build_bucket_table(&tb, bidirectional, num_buckets, max_distance);
+  if (rc) return rc;
+  REQUIRE(n >= 0 && units >= 0 && ((out && weight && rel) || n * units == 0), "bad arguments");
+  launch_bucket_embedding(out, weight, rel, dtype, n, units, tb, S(stream));
+  return check_launch("gnlp_bucket_embedding");
+}
+
+int gnlp_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq, int64_t Lm,
+                     int bidirectional, int num_buckets, int max_distance, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  BucketTable tb;
+  int rc = build_bucket_table(&tb, bidirectional, num_buckets, max_distance);
+  if (rc) return rc;
+  REQUIRE(H >= 0 && Lq >= 0 && Lm >= 0 && ((out && weight) || H * Lq * Lm == 0), "bad arguments");
+  launch_t5_rel_bias(out, weight, dtype, H, Lq, Lm, tb, S(stream));
+  return check_launch("gnlp_t5_rel_bias");
+}
+
+size_t gnlp_ffn_workspace_bytes(const gnlp_ffn_cfg *cfg, int64_t rows) {
+  if (!cfg || rows < 0) return 0;
+  return ffn_ws(cfg, rows).total;
+}
+
+int gnlp_positionwise_ffn(void *out, const void *x, const gnlp_ffn_params *p,
+                          const gnlp_ffn_cfg *cfg, int64_t rows, const void *valid_length,
+                          int vl_dtype, int64_t B, int64_t L, int time_major, void *workspace,
+                          size_t workspace_bytes, gnlp_stream_t stream) {
+  REQUIRE(p && cfg, "NULL params / cfg");
+  REQUIRE(dtype_ok(cfg->dtype), "unsupported dtype %d", cfg->dtype);
+  REQUIRE(cfg->units > 0 && cfg->hidden > 0 && rows >= 0, "bad shape");
+  REQUIRE(cfg->act >= GNLP_ACT_IDENTITY && cfg->act <= GNLP_ACT_SOFTSIGN,
+          "act=%d is not supported", cfg->act);
+  REQUIRE(cfg->norm_kind >= GNLP_NORM_LAYER && cfg->norm_kind <= GNLP_NORM_NONE,
+          "normalization kind %d is not supported", cfg->norm_kind);
+  REQUIRE(p->ffn1_w && p->ffn2_w && p->ln_g, "missing ffn weights");
+  REQUIRE(!cfg->gated || p->gate_w, "gated FFN without gated_ffn_1 weight");
+  REQUIRE(!valid_length || (vl_ok(vl_dtype) && B * L == rows), "bad valid_length arguments");
+  if (rows == 0) return GNLP_OK;
+  REQUIRE(out && x && out != x, "NULL or aliased tensors");
+  return ffn_impl(out, x, p, cfg, rows, valid_length, vl_dtype, B, L, time_major, workspace,
+                  workspace_bytes, S(stream));
+}
+
+size_t gnlp_encoder_workspace_bytes(const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                                    int want_weights) {
+  if (!cfg || B < 0 || L < 0 || cfg->heads <= 0) return 0;
+  // layer scratch + two ping-pong activations for the stack driver
+  return enc_ws(cfg, B, L, want_weights != 0).total +
+         2 * align256((size_t)B * L * cfg->units * esize(cfg->dtype));
+}
+
+int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_layer_params *p,
+                               const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                               const uint8_t *mask, const void *valid_length, int vl_dtype,
+                               void *attn_weights_out, int final_seq_mask, void *workspace,
+                               size_t workspace_bytes, gnlp_stream_t stream) {
+  int rc = check_encoder_cfg(cfg, B, L);
+  if (rc) return rc;
+  REQUIRE(p && p->qkv_w && p->proj_w && p->ln_g && p->ffn.ffn1_w && p->ffn.ffn2_w && p->ffn.ln_g,
+          "missing layer weights");
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype");
+  REQUIRE(!final_seq_mask || valid_length, "final_seq_mask needs valid_length");
+  if (B * L == 0) return GNLP_OK;
+  REQUIRE(out && x && out != x, "NULL or aliased tensors");
+  return encoder_layer_impl(out, x, p, cfg, B, L, mask, valid_length, vl_dtype, attn_weights_out,
+                            final_seq_mask, workspace, workspace_bytes, S(stream));
+}
+
+int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_layer_params *layers,
+                               int n_layers, const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                               const void *valid_length, int vl_dtype, int final_seq_mask,
+                               void *const *all_encodings, void *workspace, size_t workspace_bytes,
+                               gnlp_stream_t stream) {
+  int rc = check_encoder_cfg(cfg, B, L);
+  if (rc) return rc;
+  REQUIRE(layers && n_layers >= 1, "no layers");
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype");
+  REQUIRE(!final_seq_mask || valid_length, "final_seq_mask needs valid_length");
+  if (B * L == 0) return GNLP_OK;
+  REQUIRE(x && (out || all_encodings), "NULL tensors");
+  const size_t act_bytes = align256((size_t)B * L * cfg->units * esize(cfg->dtype));
+  const size_t layer_bytes = enc_ws(cfg, B, L, false).total;
+  REQUIRE(workspace && workspace_bytes >= layer_bytes + 2 * act_bytes,
+          "encoder stack workspace too small: need %zu bytes, got %zu", layer_bytes + 2 * act_bytes,
+          workspace_bytes);
+  char *base = (char *)workspace;
+  void *pp[2] = {base + layer_bytes, base + layer_bytes + act_bytes};
+  const void *in = x;
+  for (int i = 0; i < n_layers; ++i) {
+    void *dst;
+    if (all_encodings) dst = all_encodings[i];
+    else dst = (i == n_layers - 1) ? out : pp[i & 1];
+    REQUIRE(dst && dst != in, "NULL or aliased layer output");
+    const gnlp_encoder_layer_params *p = &layers[i];
+    REQUIRE(p->qkv_w && p->proj_w && p->ln_g && p->ffn.ffn1_w && p->ffn.ffn2_w && p->ffn.ln_g,
+            "missing weights in layer %d", i);
+    // bert.py:300-304: with output_all_encodings every layer output is masked and fed on
+    const int seqm = final_seq_mask && (all_encodings || i == n_layers - 1);
+    rc = encoder_layer_impl(dst, in, p, cfg, B, L, nullptr, valid_length, vl_dtype, nullptr, seqm,
+                            base, layer_bytes, S(stream));
+    if (rc) return rc;
+    in = dst;
+  }
+  return GNLP_OK;
+}
+
+// ---- T5 ------------------------------------------------------------------------------------------
+namespace {
+struct T5Ws { size_t normed, qkv, ctx, h1, ffn, total; };
+gnlp_ffn_cfg t5_ffn_cfg(const gnlp_t5_cfg *c) {
+  gnlp_ffn_cfg f;
+  f.units = c->d_model; f.hidden = c->d_ff;
+  f.act = c->gated ? GNLP_ACT_GELU_TANH : GNLP_ACT_RELU;   // t5.py:341-342
+  f.gated = c->gated; f.norm_kind = GNLP_NORM_RMS; f.pre_norm = 1; f.dtype = c->dtype;
+  f.ln_eps = 1e-6f;  // layers.py:67-68: epsilon is not forwarded to RMSNorm (default 1e-6)
+  return f;
+}
+T5Ws t5_ws(const gnlp_t5_cfg *c, int64_t B, int64_t L) {
+  T5Ws w;
+  const size_t e = esize(c->dtype);
+  const int64_t M = B * L, inner = c->heads * c->d_kv;
+  size_t off = 0;
+  w.normed = off; off += align256((size_t)M * c->d_model * e);
+  w.qkv = off; off += align256((size_t)M * 3 * inner * e);
+  w.ctx = off; off += align256((size_t)M * inner * e);
+  w.h1 = off; off += align256((size_t)M * c->d_model * e);
+  w.ffn = off;
+  gnlp_attn_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = B; d.H = c->heads; d.Lq = L; d.Lm = L; d.dk = d.dv = c->d_kv;
+  const bool fused = c->dtype == GNLP_BF16 && c->d_kv == 64;
+  size_t attn = attn_ws_bytes(&d, c->dtype, false, false, fused);
+  gnlp_ffn_cfg f = t5_ffn_cfg(c);
+  size_t ffn = ffn_ws(&f, M).total;
+  off += attn > ffn ? attn : ffn;   // attention scratch and FFN scratch are never live together
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+size_t gnlp_t5_workspace_bytes(const gnlp_t5_cfg *cfg, int64_t B, int64_t L) {
+  if (!cfg || B < 0 || L < 0) return 0;
+  return t5_ws(cfg, B, L).total + 2 * align256((size_t)B * L * cfg->d_model * esize(cfg->dtype));
+}
+
+int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params *layers,
+                            int n_layers, const void *final_ln_g, const void *final_ln_b,
+                            const gnlp_t5_cfg *cfg, int64_t B, int64_t L, const void *valid_length,
+                            int vl_dtype, const void *position_bias, void *workspace,
+                            size_t workspace_bytes, gnlp_stream_t stream) {
+  REQUIRE(cfg && layers && n_layers >= 1, "NULL cfg / layers");
+  REQUIRE(dtype_ok(cfg->dtype), "unsupported dtype %d", cfg->dtype);
+  REQUIRE(cfg->d_model > 0 && cfg->d_kv > 0 && cfg->d_ff > 0 && cfg->heads > 0, "bad T5 sizes");
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype");
+  REQUIRE(B >= 0 && L >= 0, "negative shape");
+  if (B * L == 0) return GNLP_OK;
+  REQUIRE(out && x, "NULL tensors");
+  const T5Ws w = t5_ws(cfg, B, L);
+  const size_t e = esize(cfg->dtype);
+  const int64_t M = B * L, D = cfg->d_model, H = cfg->heads, dkv = cfg->d_kv, inner = H * dkv;
+  const size_t act_bytes = align256((size_t)M * D * e);
+  REQUIRE(workspace && workspace_bytes >= w.total + 2 * act_bytes,
+          "t5 workspace too small: need %zu bytes, got %zu", w.total + 2 * act_bytes,
+          workspace_bytes);
+  hipStream_t s = S(stream);
+  char *base = (char *)workspace;
+  void *pp[2] = {base + w.total, base + w.total + act_bytes};
+  gnlp_ffn_cfg f = t5_ffn_cfg(cfg);
+  const void *h = x;
+  int rc;
+  for (int i = 0; i < n_layers; ++i) {
+    const gnlp_t5_block_params *p = &layers[i];
+    REQUIRE(p->attn_ln_g && p->q_w && p->k_w && p->v_w && p->proj_w && p->ffn.ffn1_w &&
+            p->ffn.ffn2_w && p->ffn.ln_g, "missing weights in T5 block %d", i);
+    const bool last = (i == n_layers - 1);
+    void *dst = (last && !final_ln_g) ? out : pp[i & 1];
+    // t5.py:537  out = self_attn_layer_norm(hidden)
+    launch_norm(base + w.normed, h, nullptr, p->attn_ln_g, p->attn_ln_b, cfg->dtype, GNLP_NORM_RMS,
+                cfg->ln_eps, M, D, nullptr, 0, 0, 0, 0, s);
+    // t5.py:538-542  bias-free q / k / v projections written side by side: [q | k | v] rows
+    char *qkv = base + w.qkv;
+    const void *wq[3] = {p->q_w, p->k_w, p->v_w};
+    for (int t = 0; t < 3; ++t) {
+      rc = dense_impl(qkv + (size_t)t * inner * e, base + w.normed, wq[t], nullptr, nullptr, 0,
+                      GNLP_ACT_IDENTITY, cfg->dtype, M, inner, D, D, 3 * inner, 0, s);
+      if (rc) return rc;
+    }
+    gnlp_attn_desc ad;
+    ad.B = B; ad.H = H; ad.Lq = L; ad.Lm = L; ad.dk = dkv; ad.dv = dkv;
+    const int64_t sb = cfg->time_major ? 1 : L, st = cfg->time_major ? B : 1;
+    ad.q_stride[0] = ad.k_stride[0] = ad.v_stride[0] = sb * 3 * inner;
+    ad.q_stride[1] = ad.k_stride[1] = ad.v_stride[1] = dkv;
+    ad.q_stride[2] = ad.k_stride[2] = ad.v_stride[2] = st * 3 * inner;
+    ad.o_stride[0] = sb * inner; ad.o_stride[1] = dkv; ad.o_stride[2] = st * inner;
+    const int64_t estr[4] = {0, L * L, L, 1};
+    // t5.py:543-549  scaled=False (ctor :261-270), edge_scores = position_embeddings
+    rc = attn_impl(base + w.ctx, nullptr, nullptr, qkv, qkv + (size_t)inner * e,
+                   qkv + (size_t)2 * inner * e, &ad, cfg->dtype, nullptr, nullptr, valid_length,
+                   vl_dtype, position_bias, position_bias ? estr : nullptr, 0.0f, base + w.ffn,
+                   w.total - w.ffn, s);
+    if (rc) return rc;
+    // t5.py:550-551  hidden = hidden + proj(out)
+    rc = dense_impl(base + w.h1, base + w.ctx, p->proj_w, nullptr, h, GNLP_COMBINE_ADD,
+                    GNLP_ACT_IDENTITY, cfg->dtype, M, D, inner, inner, D, D, s);
+    if (rc) return rc;
+    // t5.py:571  ffn (pre-norm RMS, residual inside)
+    rc = ffn_impl(dst, base + w.h1, &p->ffn, &f, M, nullptr, 0, 0, 0, 0, base + w.ffn,
+                  w.total - w.ffn, s);
+    if (rc) return rc;
+    h = dst;
+  }
+  if (final_ln_g) {  // t5.py:709
+    launch_norm(out, h, nullptr, final_ln_g, final_ln_b, cfg->dtype, GNLP_NORM_RMS, cfg->ln_eps, M,
+                D, nullptr, 0, 0, 0, 0, s);
+  }
+  return check_launch("gnlp_t5_encoder_forward");
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// Fused multi-head dot-product attention forward for gfx950 (bf16, d_k = d_v = 64).
+// Reference: multi_head_dot_attn, attention_cell.py:332-524 --
+//   scores = Q K^T (+ edge_scores);  w = masked_softmax(scores, mask, temperature);  ctx = w V
+// computed flash-style: the (B, H, Lq, Lm) tensor is never written to HBM.
+//
+// Work decomposition: one 256-thread workgroup = 128 query rows of one (batch, head); each of the
+// 4 waves owns 32 query rows.  K / V tiles of 64 keys are staged into double-buffered LDS with
+// 16-byte direct-to-LDS loads and shared by the 4 waves.
+//   S^T = K . Q^T  with v_mfma_f32_32x32x16_bf16 (A = K rows via ds_read_b128 from an XOR-swizzled
+//         image, B = Q held in registers): a lane owns ONE query row (column l&31) and 16 of the
+//         32 keys of each key block, so the softmax needs a single cross-lane exchange (lane^32).
+//   O^T = V^T . P^T: the S^T accumulator, converted pairwise to bf16, is directly the B operand
+//         (no LDS round trip); V^T fragments come from the row-major V image with the hardware
+//         transposing read ds_read_b64_tr_b16.
+// The NKT / NTK / TNK layouts and the fused-QKV buffer are stride descriptors.  The mask is either
+// the valid_length predicate (tiles beyond valid_length are skipped entirely, padded query rows
+// produce exact zeros) or a dense byte mask; edge_scores (T5 bias) is added before the
+// temperature (attention_cell.py:453-455).
+#include "common.h"
+#include "kernels.h"
+
+namespace gnlp {
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+typedef __attribute__((address_space(3))) bf16x4 *lds_bf16x4_ptr;
+
+constexpr int KV_TILE = 64;
+constexpr int TILE_BYTES = KV_TILE * 128;   // 64 keys x 64 bf16
+constexpr float NEG_BIG = -1.0e30f;
+
+template <bool HAS_BIAS, bool DENSE_MASK>
+__global__ void __launch_bounds__(256, 2)
+attn_fwd_bf16_d64(FusedAttn a) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int64_t b = blockIdx.z, h = blockIdx.y;
+  const int64_t q0 = (int64_t)blockIdx.x * 128;
+
+  int64_t kv_len = a.Lm;
+  int64_t q_valid = a.Lq;
+  const bool use_pred = !DENSE_MASK && (a.vl != nullptr);
+  if (use_pred) {
+    int64_t n = load_len(a.vl, a.vl_dtype, b);
+    n = n < 0 ? 0 : n;
+    kv_len = n < a.Lm ? n : a.Lm;
+    q_valid = n < a.Lq ? n : a.Lq;
+  }
+  const int64_t my_q = q0 + wave * 32 + r;  // this lane's query row
+  bf16 *const obase = (bf16 *)a.o + b * a.os[0] + h * a.os[1];
+  const int ntiles = (int)((kv_len + KV_TILE - 1) / KV_TILE);
+
+  if (q0 >= q_valid || ntiles == 0) {  // block-uniform: every query row of the block is padded
+    if (my_q < a.Lq) {
+      bf16x4 z = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        *reinterpret_cast<bf16x4 *>(obase + my_q * a.os[2] + g * 8 + hh * 4) = z;
+    }
+    return;
+  }
+
+  // ---- Q fragments (B operand of S^T = K Q^T): Q[my_q][16 s + 8 hh .. +8] ----
+  const int64_t qrow = my_q < a.Lq ? my_q : a.Lq - 1;
+  const bf16 *qp = (const bf16 *)a.q + b * a.qs[0] + h * a.qs[1] + qrow * a.qs[2];
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s + 8 * hh);
+
+  // ---- staging: each wave moves 2 K pieces and 2 V pieces (8 rows x 128 B each) per tile ----
+  const int srow = lane >> 3, cpos = lane & 7;
+  const bf16 *kbase = (const bf16 *)a.k + b * a.ks[0] + h * a.ks[1];
+  const bf16 *vbase = (const bf16 *)a.v + b * a.vs[0] + h * a.vs[1];
+  auto stage = [&](int buf, int tile) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int piece = wave * 2 + t;
+      const int row = piece * 8 + srow;
+      int64_t key = (int64_t)tile * KV_TILE + row;
+      if (key > a.Lm - 1) key = a.Lm - 1;
+      const int ck = cpos ^ ((row >> 1) & 7);          // K image: b128 row reads
+      const int cv = cpos ^ (((row >> 1) & 1) << 2);   // V image: transposed b64 reads
+      __builtin_amdgcn_global_load_lds((gptr_t)(kbase + key * a.ks[2] + ck * 8),
+                                       (lptr_t)(smem + buf * TILE_BYTES + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vbase + key * a.vs[2] + cv * 8),
+                                       (lptr_t)(smem + (2 + buf) * TILE_BYTES + piece * 1024), 16,
+                                       0, 0);
+    }
+  };
+
+  // K fragment (A operand): row = kb*32 + r, 16-byte chunk 2s + hh
+  const int k_off = r * 128;
+  const int k_sw = (r >> 1) & 7;
+  // V^T fragment via ds_read_b64_tr_b16: lane (i = l&15 -> q4 = i>>2, p = i&3; G = l>>4):
+  //   key = 16 s + 4 hh + q4 (+8), column = dvb*32 + (G&1)*16 + 4 p
+  const int v_q4 = (lane & 15) >> 2, v_p = lane & 3, v_g1 = (lane >> 4) & 1;
+  const int v_row0 = 4 * hh + v_q4;                      // + 16 s (+ 8)
+  const int v_colb = (v_g1 * 16 + 4 * v_p) * 2;          // byte column inside a 64-byte half
+  const int v_sw = ((v_row0 >> 1) & 1) << 6;             // same for row0 + 8 and + 16 s
+
+  const float c_scale = a.inv_temperature * 1.44269504088896340736f;
+  float m_run = NEG_BIG, l_run = 0.0f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.0f;
+
+  const bool row_ok = my_q < q_valid;
+  const uint8_t *mrow = DENSE_MASK ? a.mask + b * a.ms[0] + qrow * a.ms[1] : nullptr;
+  const bf16 *brow = HAS_BIAS ? (const bf16 *)a.bias + b * a.bs[0] + h * a.bs[1] + qrow * a.bs[2]
+                              : nullptr;
+
+  stage(0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) stage(cur ^ 1, tile + 1);
+    const char *kt = smem + cur * TILE_BYTES;
+    const char *vt = smem + (2 + cur) * TILE_BYTES;
+
+    // ---- S^T = K Q^T : sacc[kb][reg] = score(key = kb*32 + (reg&3) + 8*(reg>>2) + 4*hh, my_q) ----
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kt + kb * 4096 + k_off +
+                                                      (((2 * s + hh) ^ k_sw) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- bias, mask, online softmax (one query row per lane, keys split with lane^32) ----
+    const int64_t kbase_idx = (int64_t)tile * KV_TILE;
+    const bool tail = DENSE_MASK || (kbase_idx + KV_TILE > kv_len);
+    float mloc = NEG_BIG;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t j0 = kbase_idx + kb * 32 + g * 8 + hh * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_BIAS) {  // host guarantees unit stride, Lm % 4 == 0 and 8-byte alignment
+          if (j0 < a.Lm) {
+            bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(brow + j0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float z = (sacc[kb][g * 4 + e] + bv[e]) * c_scale;
+          if (tail) {
+            bool on = (j0 + e) < kv_len;
+            if (DENSE_MASK && on) on = mrow[(j0 + e) * a.ms[2]] != 0;
+            z = on ? z : NEG_BIG;
+          }
+          sacc[kb][g * 4 + e] = z;
+          mloc = fmaxf(mloc, z);
+        }
+      }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.0f;
+    bf16x8 pf[4];  // B operand fragments of O^T = V^T P^T, k-step s = 2 kb + t
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float z = sacc[kb][e];
+        float p = __builtin_amdgcn_exp2f(z - m_new);
+        p = (z > -1.0e29f && row_ok) ? p : 0.0f;
+        psum += p;
+        pf[2 * kb + (e >> 3)][e & 7] = (bf16)p;
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int off0 = (16 * s + v_row0) * 128 + ((d * 64 + v_colb) ^ v_sw);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vt + off0));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vt + off0 + 8 * 128));
+        bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- finalize: O / l, lane holds ctx[my_q][d*32 + 8 g + 4 hh .. +3] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (my_q < a.Lq) {
+    bf16 *op = obase + my_q * a.os[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[d][g * 4 + e] * inv_l);
+        *reinterpret_cast<bf16x4 *>(op + d * 32 + g * 8 + hh * 4) = o;
+      }
+  }
+}
+
+bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv) {
+  if (dk != 64 || dv != 64) return false;
+  if (a.B < 1 || a.H < 1 || a.Lq < 1 || a.Lm < 1) return false;
+  if (a.H > 65535 || a.B > 65535) return false;
+  // 16-byte aligned rows for q / k / v, 8-byte for the output
+  const int64_t *ss[3] = {a.qs, a.ks, a.vs};
+  for (int t = 0; t < 3; ++t)
+    for (int e = 0; e < 3; ++e)
+      if (ss[t][e] % 8 != 0) return false;
+  for (int e = 0; e < 3; ++e)
+    if (a.os[e] % 4 != 0) return false;
+  if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 != 0) return false;
+  if (a.bias) {  // vector loads of 4 consecutive keys of the bias row
+    if (a.bs[3] != 1 || a.Lm % 4 != 0 || (uintptr_t)a.bias % 8 != 0) return false;
+    for (int e = 0; e < 3; ++e)
+      if (a.bs[e] % 4 != 0) return false;
+  }
+  if ((uintptr_t)a.o % 8 != 0) return false;
+  return true;
+}
+
+void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s) {
+  dim3 grid((unsigned)((a.Lq + 127) / 128), (unsigned)a.H, (unsigned)a.B);
+  if (a.bias) {
+    if (a.mask) attn_fwd_bf16_d64<true, true><<<grid, 256, 0, s>>>(a);
+    else attn_fwd_bf16_d64<true, false><<<grid, 256, 0, s>>>(a);
+  } else {
+    if (a.mask) attn_fwd_bf16_d64<false, true><<<grid, 256, 0, s>>>(a);
+    else attn_fwd_bf16_d64<false, false><<<grid, 256, 0, s>>>(a);
+  }
+}
+
+}  // namespace gnlp

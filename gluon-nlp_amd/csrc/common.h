@@ -1,0 +1,81 @@
+// Shared device helpers for the gfx950 kernels (wave64, bf16 <-> fp32, reductions, activations).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gluonnlp_amd.h"
+
+namespace gnlp {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kWave = 64;
+
+template <typename T> struct VecOf;   // 16-byte vector of T
+template <> struct VecOf<float> { typedef f32x4 type; static constexpr int N = 4; };
+template <> struct VecOf<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ int64_t load_len(const void *p, int vl_dtype, int64_t i) {
+  return vl_dtype == GNLP_I64 ? ((const int64_t *)p)[i] : (int64_t)((const int32_t *)p)[i];
+}
+
+// layers.py:236-338.  EXACT selects erff (fp32 tolerance path); the bf16 path may use the
+// cheaper rational erf (|err| < 1.5e-7, far below bf16 resolution).
+__device__ __forceinline__ float erf_fast(float x) {
+  // Abramowitz & Stegun 7.1.26
+  float ax = fabsf(x);
+  float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t +
+             0.254829592f) * t;
+  float r = 1.0f - p * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case GNLP_ACT_IDENTITY: return x;
+    case GNLP_ACT_RELU: return fmaxf(x, 0.0f);
+    case GNLP_ACT_GELU_ERF: {
+      float e = EXACT ? erff(x * 0.70710678118654752440f) : erf_fast(x * 0.70710678118654752440f);
+      return 0.5f * x * (1.0f + e);
+    }
+    case GNLP_ACT_GELU_TANH: {
+      float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+      return 0.5f * x * (1.0f + tanhf(u));
+    }
+    case GNLP_ACT_GELU_SIGMOID: return x / (1.0f + expf(-1.702f * x));
+    case GNLP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case GNLP_ACT_TANH: return tanhf(x);
+    case GNLP_ACT_LEAKY: return x > 0.0f ? x : 0.1f * x;
+    case GNLP_ACT_ELU: return x > 0.0f ? x : expm1f(x);
+    case GNLP_ACT_SOFTRELU: return log1pf(expf(-fabsf(x))) + fmaxf(x, 0.0f);
+    case GNLP_ACT_SOFTSIGN: return x / (1.0f + fabsf(x));
+    default: return x;
+  }
+}
+
+}  // namespace gnlp

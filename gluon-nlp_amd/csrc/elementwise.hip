@@ -1,0 +1,294 @@
+// HBM-bound integer / elementwise kernels of the encoder path (gfx950):
+// mask generation, sequence_mask, activations, l2_normalize, T5 relative-position buckets.
+// All are coalesced 16-byte-per-lane streaming kernels; none uses LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace gnlp {
+
+// ------------------------------------------------------------------------------------------
+// gen_self_attn_mask / gen_mem_attn_mask   (attention_cell.py:40-183, 186-274)
+// One thread writes 16 consecutive mask bytes of the flat (B, Lq, Lm) array.
+// ------------------------------------------------------------------------------------------
+template <int MODE>  // 0 = self/full, 1 = self/causal, 2 = mem
+__global__ void __launch_bounds__(256)
+mask_kernel(uint8_t *__restrict__ mask, const void *__restrict__ vl_k, const void *__restrict__ vl_q,
+            int vl_dtype, int64_t B, int64_t Lq, int64_t Lm) {
+  const int64_t total = B * Lq * Lm;
+  int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (base >= total) return;
+  int64_t j = base % Lm;
+  int64_t r = base / Lm;
+  int64_t i = r % Lq;
+  int64_t b = r / Lq;
+  int64_t nk = vl_k ? load_len(vl_k, vl_dtype, b) : Lm;
+  int64_t nq = vl_q ? load_len(vl_q, vl_dtype, b) : Lq;
+  uint32_t w[4] = {0, 0, 0, 0};
+  const int n = (int)((total - base) < 16 ? (total - base) : 16);
+  for (int e = 0; e < n; ++e) {
+    bool on;
+    if (MODE == 1) on = (j <= i) && (i < nq);
+    else on = (j < nk) && (i < nq);
+    w[e >> 2] |= (on ? 1u : 0u) << (8 * (e & 3));
+    if (++j == Lm) {
+      j = 0;
+      if (++i == Lq) {
+        i = 0;
+        ++b;
+        if (b < B) {
+          nk = vl_k ? load_len(vl_k, vl_dtype, b) : Lm;
+          nq = vl_q ? load_len(vl_q, vl_dtype, b) : Lq;
+        }
+      }
+    }
+  }
+  if (n == 16) {
+    *reinterpret_cast<uint4 *>(mask + base) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    for (int e = 0; e < n; ++e) mask[base + e] = (uint8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xff);
+  }
+}
+
+void launch_self_mask(uint8_t *mask, const void *vl, int vl_dtype, int64_t B, int64_t L,
+                      int attn_type, hipStream_t s) {
+  const int64_t total = B * L * L;
+  if (total == 0) return;
+  const int64_t threads = (total + 15) / 16;
+  dim3 grid((unsigned)((threads + 255) / 256));
+  if (attn_type == GNLP_ATTN_CAUSAL)
+    mask_kernel<1><<<grid, 256, 0, s>>>(mask, nullptr, vl, vl_dtype, B, L, L);
+  else
+    mask_kernel<0><<<grid, 256, 0, s>>>(mask, vl, vl, vl_dtype, B, L, L);
+}
+
+void launch_mem_mask(uint8_t *mask, const void *mem_vl, const void *data_vl, int vl_dtype,
+                     int64_t B, int64_t Lq, int64_t Lm, hipStream_t s) {
+  const int64_t total = B * Lq * Lm;
+  if (total == 0) return;
+  const int64_t threads = (total + 15) / 16;
+  dim3 grid((unsigned)((threads + 255) / 256));
+  mask_kernel<2><<<grid, 256, 0, s>>>(mask, mem_vl, data_vl, vl_dtype, B, Lq, Lm);
+}
+
+// ------------------------------------------------------------------------------------------
+// sequence_mask   (npx.sequence_mask at models/bert.py:311-312)
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256)
+seqmask_kernel(T *__restrict__ out, const T *__restrict__ x, const void *__restrict__ vl,
+               int vl_dtype, int64_t B, int64_t L, int64_t C, int time_major) {
+  constexpr int N = VEC ? VecOf<T>::N : 1;
+  const int64_t total = B * L * C;
+  int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * N;
+  if (e0 >= total) return;
+  const int64_t row = e0 / C;
+  const int64_t b = time_major ? row % B : row / L;
+  const int64_t t = time_major ? row / B : row % L;
+  const bool keep = t < load_len(vl, vl_dtype, b);
+  if (VEC) {
+    typedef typename VecOf<T>::type V;
+    V v = *reinterpret_cast<const V *>(x + e0);
+    if (!keep) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) v[q] = (T)0.0f;
+    }
+    *reinterpret_cast<V *>(out + e0) = v;
+  } else {
+    out[e0] = keep ? x[e0] : (T)0.0f;
+  }
+}
+
+template <typename T>
+static void seqmask_t(void *out, const void *x, const void *vl, int vl_dtype, int64_t B, int64_t L,
+                      int64_t C, int time_major, hipStream_t s) {
+  const int64_t total = B * L * C;
+  if (total == 0) return;
+  const bool vec = (C % VecOf<T>::N == 0) && (((uintptr_t)out | (uintptr_t)x) % 16 == 0);
+  if (vec) {
+    int64_t threads = total / VecOf<T>::N;
+    seqmask_kernel<T, true><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(
+        (T *)out, (const T *)x, vl, vl_dtype, B, L, C, time_major);
+  } else {
+    seqmask_kernel<T, false><<<dim3((unsigned)((total + 255) / 256)), 256, 0, s>>>(
+        (T *)out, (const T *)x, vl, vl_dtype, B, L, C, time_major);
+  }
+}
+
+void launch_sequence_mask(void *out, const void *x, const void *vl, int vl_dtype, int dtype,
+                          int64_t B, int64_t L, int64_t C, int time_major, hipStream_t s) {
+  if (dtype == GNLP_BF16) seqmask_t<bf16>(out, x, vl, vl_dtype, B, L, C, time_major, s);
+  else seqmask_t<float>(out, x, vl, vl_dtype, B, L, C, time_major, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// activations   (layers.py:236-338)
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256)
+act_kernel(T *__restrict__ out, const T *__restrict__ x, int64_t n, int act) {
+  constexpr int N = VEC ? VecOf<T>::N : 1;
+  int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * N;
+  if (e0 >= n) return;
+  if (VEC) {
+    typedef typename VecOf<T>::type V;
+    V v = *reinterpret_cast<const V *>(x + e0);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = from_f32<T>(apply_act<true>(to_f32(v[q]), act));
+    *reinterpret_cast<V *>(out + e0) = v;
+  } else {
+    out[e0] = from_f32<T>(apply_act<true>(to_f32(x[e0]), act));
+  }
+}
+
+template <typename T>
+static void act_t(void *out, const void *x, int64_t n, int act, hipStream_t s) {
+  if (n == 0) return;
+  const bool vec = (n % VecOf<T>::N == 0) && (((uintptr_t)out | (uintptr_t)x) % 16 == 0);
+  if (vec) {
+    int64_t threads = n / VecOf<T>::N;
+    act_kernel<T, true><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>((T *)out,
+                                                                                 (const T *)x, n, act);
+  } else {
+    act_kernel<T, false><<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>((T *)out, (const T *)x,
+                                                                            n, act);
+  }
+}
+
+void launch_activation(void *out, const void *x, int dtype, int64_t n, int act, hipStream_t s) {
+  if (dtype == GNLP_BF16) act_t<bf16>(out, x, n, act, s);
+  else act_t<float>(out, x, n, act, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// l2_normalize   (op.py:289-307):  x / (||x||_2 + eps), one row per wave
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+l2norm_kernel(T *__restrict__ out, const T *__restrict__ x, int64_t rows, int64_t d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T *xr = x + row * d;
+  float ss = 0.0f;
+  for (int64_t c = lane; c < d; c += 64) {
+    float v = to_f32(xr[c]);
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / (sqrtf(ss) + eps);
+  T *orow = out + row * d;
+  for (int64_t c = lane; c < d; c += 64) orow[c] = from_f32<T>(to_f32(xr[c]) * inv);
+}
+
+void launch_l2_normalize(void *out, const void *x, int dtype, int64_t rows, int64_t d, float eps,
+                         hipStream_t s) {
+  if (rows == 0 || d == 0) return;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == GNLP_BF16)
+    l2norm_kernel<bf16><<<grid, 256, 0, s>>>((bf16 *)out, (const bf16 *)x, rows, d, eps);
+  else
+    l2norm_kernel<float><<<grid, 256, 0, s>>>((float *)out, (const float *)x, rows, d, eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// T5 relative positions   (attention_cell.py:611-656, op.py:229-286, layers.py:519-524)
+//
+// The bucket of a distance n >= max_exact is max_exact + trunc(logf(n/max_exact)/log(md/me)*(nb-me))
+// in float32.  That map is monotone in n, so the host evaluates it (same libm logf as the
+// reference's CPU path) only to find the integer thresholds where the bucket increments, and the
+// device does pure integer compares: bit-exact by construction, no device transcendental.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bucket_of(int rel, const BucketTable &tb) {
+  int n = -rel;  // op.py:262
+  int ret = 0;
+  if (tb.bidirectional) {
+    if (n < 0) ret = tb.half;  // op.py:267
+    n = n < 0 ? -n : n;        // op.py:268
+  } else {
+    n = n < 0 ? 0 : n;         // op.py:271
+  }
+  int v;
+  if (n < tb.max_exact) {
+    v = n;
+  } else {
+    v = tb.max_exact;
+    for (int q = 0; q < tb.n_thr; ++q) v += (n >= tb.thr[q]) ? 1 : 0;
+  }
+  return ret + v;
+}
+
+__global__ void __launch_bounds__(256)
+rel_position_kernel(int32_t *__restrict__ out, int64_t L) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L * L) return;
+  out[idx] = (int32_t)(idx % L) - (int32_t)(idx / L);  // mem_j - query_i
+}
+
+void launch_rel_position(int32_t *out, int64_t L, hipStream_t s) {
+  if (L == 0) return;
+  rel_position_kernel<<<dim3((unsigned)((L * L + 255) / 256)), 256, 0, s>>>(out, L);
+}
+
+__global__ void __launch_bounds__(256)
+bucket_kernel(int32_t *__restrict__ out, const int32_t *__restrict__ rel, int64_t n,
+              BucketTable tb) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  out[idx] = bucket_of(rel[idx], tb);
+}
+
+void launch_bucket(int32_t *out, const int32_t *rel, int64_t n, const BucketTable &tb,
+                   hipStream_t s) {
+  if (n == 0) return;
+  bucket_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>(out, rel, n, tb);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+bucket_embed_kernel(T *__restrict__ out, const T *__restrict__ weight,
+                    const int32_t *__restrict__ rel, int64_t n, int64_t units, BucketTable tb) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * units) return;
+  const int64_t i = idx / units, u = idx % units;
+  out[idx] = weight[(int64_t)bucket_of(rel[i], tb) * units + u];
+}
+
+void launch_bucket_embedding(void *out, const void *weight, const int32_t *rel, int dtype,
+                             int64_t n, int64_t units, const BucketTable &tb, hipStream_t s) {
+  if (n * units == 0) return;
+  dim3 grid((unsigned)((n * units + 255) / 256));
+  if (dtype == GNLP_BF16)
+    bucket_embed_kernel<bf16><<<grid, 256, 0, s>>>((bf16 *)out, (const bf16 *)weight, rel, n, units,
+                                                   tb);
+  else
+    bucket_embed_kernel<float><<<grid, 256, 0, s>>>((float *)out, (const float *)weight, rel, n,
+                                                    units, tb);
+}
+
+// out[h, i, j] = weight[bucket(j - i), h]; thread = one (h, i, j); j fastest => coalesced stores,
+// the (num_buckets, H) table stays in L1/L2.
+template <typename T>
+__global__ void __launch_bounds__(256)
+t5_bias_kernel(T *__restrict__ out, const T *__restrict__ weight, int64_t H, int64_t Lq,
+               int64_t Lm, BucketTable tb) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * Lq * Lm) return;
+  const int64_t j = idx % Lm;
+  const int64_t r = idx / Lm;
+  const int64_t i = r % Lq;
+  const int64_t h = r / Lq;
+  out[idx] = weight[(int64_t)bucket_of((int)(j - i), tb) * H + h];
+}
+
+void launch_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq,
+                        int64_t Lm, const BucketTable &tb, hipStream_t s) {
+  const int64_t total = H * Lq * Lm;
+  if (total == 0) return;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == GNLP_BF16)
+    t5_bias_kernel<bf16><<<grid, 256, 0, s>>>((bf16 *)out, (const bf16 *)weight, H, Lq, Lm, tb);
+  else
+    t5_bias_kernel<float><<<grid, 256, 0, s>>>((float *)out, (const float *)weight, H, Lq, Lm, tb);
+}
+
+}  // namespace gnlp

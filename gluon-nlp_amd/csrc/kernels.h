@@ -1,0 +1,97 @@
+// Internal launch interface between api.hip (C ABI, argument checking) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gnlp {
+
+// relative_position_bucket thresholds (see elementwise.hip); passed by value as a kernel argument
+struct BucketTable {
+  int bidirectional;
+  int half;        // num_buckets (after the bidirectional halving)
+  int max_exact;
+  int n_thr;       // number of valid thresholds
+  int thr[128];    // thr[q] = smallest n whose (unclipped) bucket is >= max_exact + q + 1
+};
+
+// elementwise.hip
+void launch_self_mask(uint8_t *mask, const void *vl, int vl_dtype, int64_t B, int64_t L,
+                      int attn_type, hipStream_t s);
+void launch_mem_mask(uint8_t *mask, const void *mem_vl, const void *data_vl, int vl_dtype,
+                     int64_t B, int64_t Lq, int64_t Lm, hipStream_t s);
+void launch_sequence_mask(void *out, const void *x, const void *vl, int vl_dtype, int dtype,
+                          int64_t B, int64_t L, int64_t C, int time_major, hipStream_t s);
+void launch_activation(void *out, const void *x, int dtype, int64_t n, int act, hipStream_t s);
+void launch_l2_normalize(void *out, const void *x, int dtype, int64_t rows, int64_t d, float eps,
+                         hipStream_t s);
+void launch_rel_position(int32_t *out, int64_t L, hipStream_t s);
+void launch_bucket(int32_t *out, const int32_t *rel, int64_t n, const BucketTable &tb,
+                   hipStream_t s);
+void launch_bucket_embedding(void *out, const void *weight, const int32_t *rel, int dtype,
+                             int64_t n, int64_t units, const BucketTable &tb, hipStream_t s);
+void launch_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq,
+                        int64_t Lm, const BucketTable &tb, hipStream_t s);
+
+// norm.hip
+void launch_norm(void *out, const void *x, const void *residual, const void *gamma,
+                 const void *beta, int dtype, int kind, float eps, int64_t rows, int64_t C,
+                 const void *vl, int vl_dtype, int64_t B, int64_t L, int time_major,
+                 hipStream_t s);
+
+// softmax.hip
+void launch_masked_softmax(void *out, const void *scores, int dtype, const uint8_t *mask,
+                           const int64_t mask_stride[4], const int64_t shape[4],
+                           const void *vl, int vl_dtype, float inv_temperature, int log_mode,
+                           hipStream_t s);
+
+// gemm_generic.hip : batched strided GEMM on the vector ALU (any shape; fp32 accumulate)
+struct GenericGemm {
+  const void *A;   // (batch, M, K): A[b0*sAb0 + b1*sAb1 + m*sAm + k]
+  const void *Bm;  // trans_b: (N, K) element (n,k) at n*sBn + k ; else (K, N): k*sBn + n
+  void *C;         // C[b0*sCb0 + b1*sCb1 + m*sCm + n]
+  const void *bias;   // (N) or null
+  const void *other;  // same addressing family as C with its own strides, or null
+  int64_t M, N, K, nb0, nb1;
+  int64_t sAb0, sAb1, sAm;
+  int64_t sBb0, sBb1, sBn;
+  int64_t sCb0, sCb1, sCm;
+  int64_t sOb0, sOb1, sOm, sOn;  // `other` strides (sOn may be 0/1; 0-strides broadcast)
+  int trans_b, act, combine, in_dtype, out_dtype, other_dtype;
+  float alpha;   // C = combine(act(alpha * A.B + bias), other)
+};
+void launch_generic_gemm(const GenericGemm &g, hipStream_t s);
+
+// gemm_bf16.hip / gemm_f32.hip : MFMA dense  out = combine(act(x.w^T + bias), other)
+bool mfma_dense_act_fused(int act);   // activations the MFMA epilogues implement
+bool mfma_bf16_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                               int64_t ldother, const void *x, const void *w, const void *out,
+                               const void *other);
+void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void *bias,
+                            const void *other, int combine, int act, int64_t M, int64_t N,
+                            int64_t K, int64_t ldx, int64_t ldo, int64_t ldother, hipStream_t s);
+bool mfma_f32_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                              int64_t ldother, const void *x, const void *w, const void *out,
+                              const void *other);
+void launch_mfma_f32_dense(void *out, const void *x, const void *w, const void *bias,
+                           const void *other, int combine, int act, int64_t M, int64_t N,
+                           int64_t K, int64_t ldx, int64_t ldo, int64_t ldother, hipStream_t s);
+
+// attn_bf16.hip : fused flash-style attention (bf16, dk = dv = 64)
+struct FusedAttn {
+  const void *q, *k, *v;
+  void *o;
+  int64_t B, H, Lq, Lm;
+  int64_t qs[3], ks[3], vs[3], os[3];   // (b, h, t) element strides
+  const uint8_t *mask;                  // or null
+  int64_t ms[3];                        // (b, i, j)
+  const void *vl;                       // or null (predicate i<vl && j<vl)
+  int vl_dtype;
+  const void *bias;                     // edge scores (bf16) or null
+  int64_t bs[4];                        // (b, h, i, j)
+  float inv_temperature;
+};
+bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv);
+void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s);
+
+}  // namespace gnlp

@@ -1,0 +1,186 @@
+// Fused (residual +) LayerNorm / RMSNorm / NoNorm (+ sequence_mask) over the last axis.
+// Reference: mxnet nn.LayerNorm as used at models/transformer.py:217-218,268-270 and
+// layers.py:63,642-646; RMSNorm layers.py:151-181; NoNorm layers.py:81-138;
+// npx.sequence_mask models/bert.py:311-312.
+//
+// HBM-bound: one wave64 owns one row, 16-byte loads per lane, the row stays in registers between
+// the statistics pass and the normalisation pass (read once, written once), statistics in fp32
+// with the two-pass (mean, then centred variance) formulation.
+#include "common.h"
+#include "kernels.h"
+
+namespace gnlp {
+
+template <typename T, int MAXV>
+__global__ void __launch_bounds__(256)
+norm_vec_kernel(T *__restrict__ out, const T *__restrict__ x, const T *__restrict__ residual,
+                const T *__restrict__ gamma, const T *__restrict__ beta, int kind, float eps,
+                int64_t rows, int C, const void *__restrict__ vl, int vl_dtype, int64_t B,
+                int64_t L, int time_major) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C / N;  // vectors per row
+  T *orow = out + row * (int64_t)C;
+  if (vl) {
+    const int64_t b = time_major ? row % B : row / L;
+    const int64_t t = time_major ? row / B : row % L;
+    if (t >= load_len(vl, vl_dtype, b)) {  // wave-uniform
+      V z;
+#pragma unroll
+      for (int q = 0; q < N; ++q) z[q] = (T)0.0f;
+      for (int v = lane; v < nvec; v += 64) *reinterpret_cast<V *>(orow + v * N) = z;
+      return;
+    }
+  }
+  const T *xr = x + row * (int64_t)C;
+  const T *rr = residual ? residual + row * (int64_t)C : nullptr;
+  float vals[MAXV][N];
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nvec) {
+      V a = *reinterpret_cast<const V *>(xr + v * N);
+      if (rr) {
+        V r = *reinterpret_cast<const V *>(rr + v * N);
+#pragma unroll
+        for (int q = 0; q < N; ++q) vals[i][q] = to_f32(a[q]) + to_f32(r[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) vals[i][q] = to_f32(a[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < N; ++q) sum += vals[i][q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < N; ++q) vals[i][q] = 0.0f;
+    }
+  }
+  float mean = 0.0f, rstd = 1.0f;
+  if (kind == GNLP_NORM_LAYER) {
+    mean = wave_sum(sum) / (float)C;
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (lane + i * 64 < nvec) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const float d = vals[i][q] - mean;
+          ss += d * d;
+        }
+      }
+    }
+    rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+  } else if (kind == GNLP_NORM_RMS) {
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) ss += vals[i][q] * vals[i][q];
+    }
+    rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nvec) {
+      V g = *reinterpret_cast<const V *>(gamma + v * N);
+      V o;
+      if (beta) {
+        V bt = *reinterpret_cast<const V *>(beta + v * N);
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+          o[q] = from_f32<T>((vals[i][q] - mean) * rstd * to_f32(g[q]) + to_f32(bt[q]));
+      } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) o[q] = from_f32<T>((vals[i][q] - mean) * rstd * to_f32(g[q]));
+      }
+      *reinterpret_cast<V *>(orow + v * N) = o;
+    }
+  }
+}
+
+// Any C / alignment: scalar loads, three passes over the (L2-resident) row.
+template <typename T>
+__global__ void __launch_bounds__(256)
+norm_scalar_kernel(T *__restrict__ out, const T *__restrict__ x, const T *__restrict__ residual,
+                   const T *__restrict__ gamma, const T *__restrict__ beta, int kind, float eps,
+                   int64_t rows, int64_t C, const void *__restrict__ vl, int vl_dtype, int64_t B,
+                   int64_t L, int time_major) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  T *orow = out + row * C;
+  if (vl) {
+    const int64_t b = time_major ? row % B : row / L;
+    const int64_t t = time_major ? row / B : row % L;
+    if (t >= load_len(vl, vl_dtype, b)) {
+      for (int64_t c = lane; c < C; c += 64) orow[c] = (T)0.0f;
+      return;
+    }
+  }
+  const T *xr = x + row * C;
+  const T *rr = residual ? residual + row * C : nullptr;
+  float mean = 0.0f, rstd = 1.0f;
+  if (kind == GNLP_NORM_LAYER) {
+    float s = 0.0f;
+    for (int64_t c = lane; c < C; c += 64) s += to_f32(xr[c]) + (rr ? to_f32(rr[c]) : 0.0f);
+    mean = wave_sum(s) / (float)C;
+    float ss = 0.0f;
+    for (int64_t c = lane; c < C; c += 64) {
+      const float d = to_f32(xr[c]) + (rr ? to_f32(rr[c]) : 0.0f) - mean;
+      ss += d * d;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+  } else if (kind == GNLP_NORM_RMS) {
+    float ss = 0.0f;
+    for (int64_t c = lane; c < C; c += 64) {
+      const float d = to_f32(xr[c]) + (rr ? to_f32(rr[c]) : 0.0f);
+      ss += d * d;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+  }
+  for (int64_t c = lane; c < C; c += 64) {
+    const float v = to_f32(xr[c]) + (rr ? to_f32(rr[c]) : 0.0f);
+    orow[c] = from_f32<T>((v - mean) * rstd * to_f32(gamma[c]) + (beta ? to_f32(beta[c]) : 0.0f));
+  }
+}
+
+template <typename T>
+static void norm_t(void *out, const void *x, const void *residual, const void *gamma,
+                   const void *beta, int kind, float eps, int64_t rows, int64_t C, const void *vl,
+                   int vl_dtype, int64_t B, int64_t L, int time_major, hipStream_t s) {
+  if (rows == 0 || C == 0) return;
+  constexpr int N = VecOf<T>::N;
+  constexpr int MAXV = 32 / N;  // 32 fp32 values per lane => C <= 2048
+  dim3 grid((unsigned)((rows + 3) / 4));
+  uintptr_t al = (uintptr_t)out | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)(beta ? beta : gamma) |
+                 (uintptr_t)(residual ? residual : x);
+  const bool vec = (C % N == 0) && (C <= 64 * N * MAXV) && (al % 16 == 0);
+  if (vec) {
+    norm_vec_kernel<T, MAXV><<<grid, 256, 0, s>>>((T *)out, (const T *)x, (const T *)residual,
+                                                  (const T *)gamma, (const T *)beta, kind, eps,
+                                                  rows, (int)C, vl, vl_dtype, B, L, time_major);
+  } else {
+    norm_scalar_kernel<T><<<grid, 256, 0, s>>>((T *)out, (const T *)x, (const T *)residual,
+                                               (const T *)gamma, (const T *)beta, kind, eps, rows,
+                                               C, vl, vl_dtype, B, L, time_major);
+  }
+}
+
+void launch_norm(void *out, const void *x, const void *residual, const void *gamma,
+                 const void *beta, int dtype, int kind, float eps, int64_t rows, int64_t C,
+                 const void *vl, int vl_dtype, int64_t B, int64_t L, int time_major,
+                 hipStream_t s) {
+  if (dtype == GNLP_BF16)
+    norm_t<bf16>(out, x, residual, gamma, beta, kind, eps, rows, C, vl, vl_dtype, B, L,
+                 time_major, s);
+  else
+    norm_t<float>(out, x, residual, gamma, beta, kind, eps, rows, C, vl, vl_dtype, B, L,
+                  time_major, s);
+}
+
+}  // namespace gnlp

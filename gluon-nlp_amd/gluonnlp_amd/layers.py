@@ -1,0 +1,387 @@
+"""Reusable blocks of the encoder path -- mirrors ``gluonnlp/layers.py`` (reference
+src/gluonnlp/layers.py): get_norm_layer / NoNorm / RMSNorm, get_activation / GELU,
+BucketPositionalEmbedding, PositionwiseFFN; plus the two MXNet layers the path uses
+(``nn.Dense(flatten=False)`` and ``nn.LayerNorm``) with MXNet's parameter names
+(weight / bias, gamma / beta) so reference state dicts load unchanged."""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import _lib
+from . import _tensor as T
+
+__all__ = ['PositionwiseFFN', 'GELU', 'get_activation', 'get_norm_layer', 'RMSNorm', 'NoNorm',
+           'LayerNorm', 'Dense', 'BucketPositionalEmbedding', 'IdentityActivation', 'Activation']
+
+
+def _empty_param(shape, dtype):
+    return nn.Parameter(torch.zeros(shape, dtype=T.torch_dtype(dtype)), requires_grad=False)
+
+
+def trunc_norm_(tensor, stdev=0.02, scale=2.0, generator=None):
+    """initializer.TruncNorm (reference src/gluonnlp/initializer.py:52-81): uniform -> erfinv ->
+    scale -> clip to +-scale*stdev."""
+    lo = (1.0 + math.erf(-scale / math.sqrt(2.0))) / 2.0
+    hi = (1.0 + math.erf(scale / math.sqrt(2.0))) / 2.0
+    u = torch.empty(tensor.shape, dtype=torch.float32, device=tensor.device)
+    u.uniform_(2 * lo - 1, 2 * hi - 1, generator=generator)
+    w = torch.erfinv(u) * (stdev * math.sqrt(2.0))
+    tensor.copy_(w.clamp_(-scale * stdev, scale * stdev).to(tensor.dtype))
+    return tensor
+
+
+# ------------------------------------------------------------------------------------------
+# activations  (layers.py:236-338)
+# ------------------------------------------------------------------------------------------
+class Activation(nn.Module):
+    """Elementwise activation evaluated by the HIP activation kernel."""
+
+    def __init__(self, act):
+        super().__init__()
+        if act not in _lib.ACT:
+            raise NotImplementedError('act={} is not supported'.format(act))
+        self._act = act
+
+    def forward(self, x):
+        xt = T.as_tensor(x)
+        dev = T.require_device(xt)
+        xt = xt.contiguous()
+        out = torch.empty_like(xt)
+        _lib.check(_lib.load().gnlp_activation(T.ptr(out), T.ptr(xt), T.code(xt), xt.numel(),
+                                               _lib.ACT[self._act], T.stream(dev)))
+        return T.like_caller(out, x)
+
+    def __repr__(self):
+        return '{}({})'.format(self.__class__.__name__, self._act)
+
+
+class IdentityActivation(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class GELU(Activation):
+    """Gaussian Error Linear Unit, mode in {'erf', 'tanh', 'sigmoid'}.  layers.py:281-338."""
+
+    def __init__(self, mode='erf'):
+        if mode not in ['erf', 'tanh', 'sigmoid']:
+            raise ValueError('Unsupported mode, only support "erf", "tanh", or "sigmoid". '
+                             'Received mode={}'.format(mode))
+        super().__init__({'erf': 'gelu', 'tanh': 'gelu(tanh)', 'sigmoid': 'gelu(sigmoid)'}[mode])
+        self._mode = mode
+
+    def __repr__(self):
+        return '{}(mode={})'.format(self.__class__.__name__, self._mode)
+
+
+def get_activation(act):
+    """layers.py:236-271."""
+    if act is None:
+        return lambda x: x
+    if isinstance(act, str):
+        if act == 'identity':
+            return IdentityActivation()
+        if act == 'gelu':
+            return GELU(mode='erf')
+        if act == 'gelu(tanh)':
+            return GELU(mode='tanh')
+        if act == 'gelu(sigmoid)':
+            return GELU(mode='sigmoid')
+        if act in ['leaky', 'elu', 'relu', 'sigmoid', 'tanh', 'softrelu', 'softsign']:
+            return Activation(act)
+        raise NotImplementedError('act={} is not supported'.format(act))
+    return act
+
+
+def _act_name(act):
+    """Name understood by the fused epilogues, or None for a user-supplied callable."""
+    if act is None:
+        return 'identity'
+    if isinstance(act, str):
+        if act not in _lib.ACT:
+            raise NotImplementedError('act={} is not supported'.format(act))
+        return act
+    return getattr(act, '_act', None)
+
+
+# ------------------------------------------------------------------------------------------
+# norms  (layers.py:38-181; mxnet nn.LayerNorm)
+# ------------------------------------------------------------------------------------------
+def _norm_call(x, gamma, beta, kind, eps, residual=None):
+    xt = T.as_tensor(x)
+    rt = T.as_tensor(residual)
+    dev = T.require_device(xt, rt, gamma, beta)
+    xt = xt.contiguous()
+    if rt is not None:
+        rt = rt.contiguous()
+    C = xt.shape[-1]
+    out = torch.empty_like(xt)
+    _lib.check(_lib.load().gnlp_norm(
+        T.ptr(out), T.ptr(xt), T.ptr(rt), T.ptr(gamma), T.ptr(beta), T.code(xt), kind, float(eps),
+        xt.numel() // max(C, 1), C, None, 0, 0, 0, 0, T.stream(dev)))
+    return T.like_caller(out, x)
+
+
+class LayerNorm(nn.Module):
+    """mxnet.gluon.nn.LayerNorm(axis=-1, epsilon, in_channels): biased variance,
+    gamma * (x - mean) / sqrt(var + eps) + beta  (used models/transformer.py:217-218)."""
+
+    def __init__(self, axis=-1, epsilon=1e-5, center=True, scale=True, in_channels=0,
+                 dtype='float32', **kwargs):
+        super().__init__()
+        assert axis == -1, 'only the last axis is supported'
+        self._epsilon = epsilon
+        self.gamma = _empty_param((in_channels,), dtype)
+        self.beta = _empty_param((in_channels,), dtype)
+        self.gamma.data.fill_(1.0)
+
+    def forward(self, data, residual=None):
+        return _norm_call(data, self.gamma.data, self.beta.data, _lib.NORM['layer_norm'],
+                          self._epsilon, residual)
+
+
+class NoNorm(nn.Module):
+    """out = gamma * data + beta.  layers.py:81-147."""
+
+    def __init__(self, in_channels, center=True, scale=True, beta_initializer='zeros',
+                 gamma_initializer='ones', dtype='float32', **kwargs):
+        super().__init__()
+        self._kwargs = {'center': center, 'scale': scale}
+        self._in_channels = in_channels
+        self.gamma = _empty_param((in_channels,), dtype)
+        self.beta = _empty_param((in_channels,), dtype)
+        self.gamma.data.fill_(1.0)
+
+    def forward(self, data):
+        return _norm_call(data, self.gamma.data, self.beta.data, _lib.NORM['no_norm'], 0.0)
+
+
+class RMSNorm(nn.Module):
+    """x * rsqrt(mean(x^2) + eps) * gamma + beta.  layers.py:151-181."""
+
+    def __init__(self, in_channels, center=True, scale=True, beta_initializer='zeros',
+                 gamma_initializer='ones', variance_epsilon=1E-6, dtype='float32', **kwargs):
+        super().__init__()
+        self._kwargs = {'center': center, 'scale': scale}
+        self._in_channels = in_channels
+        self._epsilon = variance_epsilon
+        self.gamma = _empty_param((in_channels,), dtype)
+        self.beta = _empty_param((in_channels,), dtype)
+        self.gamma.data.fill_(1.0)
+
+    def forward(self, data):
+        return _norm_call(data, self.gamma.data, self.beta.data, _lib.NORM['rms_norm'],
+                          self._epsilon)
+
+
+def get_norm_layer(normalization: str = 'layer_norm', axis: int = -1, epsilon: float = 1e-5,
+                   in_channels: int = 0, **kwargs):
+    """layers.py:38-77.  NOTE (kept from the reference): 'rms_norm' does not receive ``epsilon``."""
+    if isinstance(normalization, str):
+        if normalization == 'layer_norm':
+            return LayerNorm(axis=axis, epsilon=epsilon, in_channels=in_channels, **kwargs)
+        if normalization == 'no_norm':
+            return NoNorm(in_channels=in_channels, **kwargs)
+        if normalization == 'rms_norm':
+            return RMSNorm(in_channels=in_channels, **kwargs)
+        if normalization == 'identity':
+            return IdentityActivation()
+        raise NotImplementedError('normalization={} is not supported'.format(normalization))
+    raise NotImplementedError('The type of normalization must be str')
+
+
+def _norm_kind(layer):
+    if isinstance(layer, LayerNorm):
+        return _lib.NORM['layer_norm'], layer._epsilon
+    if isinstance(layer, RMSNorm):
+        return _lib.NORM['rms_norm'], layer._epsilon
+    if isinstance(layer, NoNorm):
+        return _lib.NORM['no_norm'], 0.0
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------
+# Dense  (mxnet nn.Dense(flatten=False))
+# ------------------------------------------------------------------------------------------
+class Dense(nn.Module):
+    """y = act(x W^T + b) with W of shape (units, in_units); optional fused ``other`` operand
+    (residual add or gate multiply)."""
+
+    def __init__(self, units, in_units, use_bias=True, flatten=False, activation=None,
+                 weight_initializer=None, bias_initializer='zeros', dtype='float32'):
+        super().__init__()
+        assert not flatten, 'only flatten=False is used on the encoder path'
+        self._units, self._in_units = units, in_units
+        self._act = _act_name(activation)
+        self.weight = _empty_param((units, in_units), dtype)
+        self.bias = _empty_param((units,), dtype) if use_bias else None
+        with torch.no_grad():
+            if callable(weight_initializer):
+                weight_initializer(self.weight.data)
+            else:
+                trunc_norm_(self.weight.data, 0.02)
+
+    def forward(self, x, other=None, combine='add', act=None, out=None):
+        xt = T.as_tensor(x)
+        ot = T.as_tensor(other)
+        w = self.weight.data
+        b = self.bias.data if self.bias is not None else None
+        dev = T.require_device(xt, ot, w, b)
+        if xt.dtype != w.dtype:
+            raise TypeError('input dtype {} != weight dtype {}'.format(xt.dtype, w.dtype))
+        xt = xt.contiguous()
+        K = xt.shape[-1]
+        assert K == self._in_units, 'last axis {} != in_units {}'.format(K, self._in_units)
+        M = xt.numel() // max(K, 1)
+        N = self._units
+        if out is None:
+            out = torch.empty(xt.shape[:-1] + (N,), dtype=xt.dtype, device=dev)
+        if ot is not None:
+            ot = ot.contiguous()
+        act = self._act if act is None else act
+        _lib.check(_lib.load().gnlp_dense(
+            T.ptr(out), T.ptr(xt), T.ptr(w), T.ptr(b), T.ptr(ot),
+            _lib.COMBINE_MUL if combine == 'mul' else _lib.COMBINE_ADD, _lib.ACT[act], T.code(xt),
+            M, N, K, K, N, N, T.stream(dev)))
+        return T.like_caller(out, x)
+
+
+# ------------------------------------------------------------------------------------------
+# BucketPositionalEmbedding  (layers.py:486-524)
+# ------------------------------------------------------------------------------------------
+class BucketPositionalEmbedding(nn.Module):
+    """T5 bucketed relative-position embedding: weight[bucket(rel)]  -> (..., units)."""
+
+    def __init__(self, units, bidirectional=True, num_buckets=32, max_distance=128,
+                 dtype='float32', embed_initializer=None):
+        super().__init__()
+        self._units = units
+        self._bidirectional = bidirectional
+        self._num_buckets = num_buckets
+        self._max_distance = max_distance
+        self._dtype = dtype
+        self.weight = _empty_param((num_buckets, units), dtype)
+        with torch.no_grad():
+            if callable(embed_initializer):
+                embed_initializer(self.weight.data)
+            else:
+                self.weight.data.normal_(0.0, 0.02)
+
+    def forward(self, relative_positions):
+        rp = T.as_tensor(relative_positions)
+        w = self.weight.data
+        dev = T.require_device(rp, w)
+        rp32 = rp.to(torch.int32).contiguous()
+        out = torch.empty(tuple(rp32.shape) + (self._units,), dtype=w.dtype, device=dev)
+        _lib.check(_lib.load().gnlp_bucket_embedding(
+            T.ptr(out), T.ptr(w), T.ptr(rp32), T.code(w), rp32.numel(), self._units,
+            int(self._bidirectional), self._num_buckets, self._max_distance, T.stream(dev)))
+        return T.like_caller(out, relative_positions)
+
+    def __repr__(self):
+        return ('{}(units={}, bidirectional={}, num_buckets={}, max_distance={}, dtype={})'
+                .format(self.__class__.__name__, self._units, self._bidirectional,
+                        self._num_buckets, self._max_distance, self._dtype))
+
+
+# ------------------------------------------------------------------------------------------
+# PositionwiseFFN  (layers.py:528-650)
+# ------------------------------------------------------------------------------------------
+def ffn_params_struct(ffn):
+    p = _lib.FfnParams()
+    p.ffn1_w = T.ptr(ffn.ffn_1.weight.data)
+    p.ffn1_b = T.ptr(ffn.ffn_1.bias.data) if ffn.ffn_1.bias is not None else None
+    if ffn._use_gated_activation:
+        p.gate_w = T.ptr(ffn.gated_ffn_1.weight.data)
+        p.gate_b = T.ptr(ffn.gated_ffn_1.bias.data) if ffn.gated_ffn_1.bias is not None else None
+    p.ffn2_w = T.ptr(ffn.ffn_2.weight.data)
+    p.ffn2_b = T.ptr(ffn.ffn_2.bias.data) if ffn.ffn_2.bias is not None else None
+    p.ln_g = T.ptr(ffn.layer_norm.gamma.data)
+    p.ln_b = T.ptr(ffn.layer_norm.beta.data)
+    return p
+
+
+class PositionwiseFFN(nn.Module):
+    """Position-wise FFN.  layers.py:528-650.
+
+    pre_norm:  norm(data) -> fc1 -> act -> fc2 -> res(+data)
+    else:      data -> fc1 -> act -> fc2 -> norm(res(+data))
+    gated:     act(gated_ffn_1(x)) * ffn_1(x)  (layers.py:636-638)."""
+
+    def __init__(self, units: int = 512, hidden_size: int = 2048, use_bias=True,
+                 activation_dropout: float = 0.0, dropout: float = 0.1, weight_initializer=None,
+                 bias_initializer='zeros', activation='relu', use_gated_activation=False,
+                 normalization: str = 'layer_norm', layer_norm_eps: float = 1E-5,
+                 pre_norm: bool = False, dtype='float32', **kwargs):
+        super().__init__()
+        self._dtype = dtype
+        self._pre_norm = pre_norm
+        self._use_gated_activation = use_gated_activation
+        self._kwargs = OrderedDict([
+            ('units', units), ('hidden_size', hidden_size),
+            ('activation_dropout', activation_dropout), ('activation', activation),
+            ('dropout', dropout), ('normalization', normalization),
+            ('layer_norm_eps', layer_norm_eps), ('pre_norm', pre_norm), ('dtype', self._dtype)])
+        self.ffn_1 = Dense(units=hidden_size, in_units=units, use_bias=use_bias,
+                           weight_initializer=weight_initializer, dtype=dtype)
+        if use_gated_activation:
+            self.gated_ffn_1 = Dense(units=hidden_size, in_units=units, use_bias=use_bias,
+                                     weight_initializer=weight_initializer, dtype=dtype)
+        self.activation = get_activation(activation)
+        self._act_name = _act_name(activation)
+        self.ffn_2 = Dense(units=units, in_units=hidden_size, use_bias=use_bias,
+                           weight_initializer=weight_initializer, dtype=dtype)
+        kwargs.pop('gamma_initializer', None)
+        self.layer_norm = get_norm_layer(in_channels=units, normalization=normalization,
+                                         epsilon=layer_norm_eps, dtype=dtype, **kwargs)
+
+    def cfg_struct(self, dtype_code):
+        kind, eps = _norm_kind(self.layer_norm)
+        c = _lib.FfnCfg()
+        c.units, c.hidden = self._kwargs['units'], self._kwargs['hidden_size']
+        c.act = _lib.ACT[self._act_name]
+        c.gated = int(self._use_gated_activation)
+        c.norm_kind, c.pre_norm, c.dtype, c.ln_eps = kind, int(self._pre_norm), dtype_code, eps
+        return c
+
+    def forward(self, data):
+        """data (..., units) -> (..., units).  One C call launches the whole block."""
+        kind, _ = _norm_kind(self.layer_norm)
+        if self._act_name is None or kind is None:
+            return self._forward_unfused(data)
+        x = T.as_tensor(data)
+        dev = T.require_device(x, self.ffn_1.weight.data)
+        x = x.contiguous()
+        U = x.shape[-1]
+        rows = x.numel() // max(U, 1)
+        out = torch.empty_like(x)
+        cfg = self.cfg_struct(T.code(x))
+        lib = _lib.load()
+        ws = T.workspace(dev, lib.gnlp_ffn_workspace_bytes(ctypes.byref(cfg), rows))
+        p = ffn_params_struct(self)
+        _lib.check(lib.gnlp_positionwise_ffn(
+            T.ptr(out), T.ptr(x), ctypes.byref(p), ctypes.byref(cfg), rows, None, 0, 0, 0, 0,
+            T.ptr(ws), 0 if ws is None else ws.numel(), T.stream(dev)))
+        return T.like_caller(out, data)
+
+    def _forward_unfused(self, data):
+        """Op-by-op path for user-supplied activation / identity normalisation (layers.py:633-647)."""
+        residual = data
+        if self._pre_norm:
+            data = self.layer_norm(data)
+        if self._use_gated_activation:
+            out = self.ffn_1(data, other=self.activation(self.gated_ffn_1(data)), combine='mul')
+        else:
+            out = self.activation(self.ffn_1(data))
+        out = self.ffn_2(out, other=residual, combine='add')
+        if not self._pre_norm:
+            out = self.layer_norm(out)
+        return out
+
+    def __repr__(self):
+        s = '{}(\n'.format(self.__class__.__name__)
+        s += ',\n'.join('\t{}={}'.format(k, v) for k, v in self._kwargs.items())
+        return s + '\n)'

@@ -1,0 +1,210 @@
+"""TransformerEncoderLayer / TransformerEncoder -- mirrors the encoder half of
+``gluonnlp/models/transformer.py`` (reference src/gluonnlp/models/transformer.py:136-385)."""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .. import _tensor as T
+from ..attention_cell import MultiHeadAttentionCell, gen_self_attn_mask, mask_predicate
+from ..layers import Dense, LayerNorm, PositionwiseFFN, ffn_params_struct
+
+__all__ = ['TransformerEncoderLayer', 'TransformerEncoder', 'run_encoder_stack']
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Transformer Encoder Layer.  models/transformer.py:136-272."""
+
+    def __init__(self, units: int = 512, hidden_size: int = 2048, num_heads: int = 8,
+                 attention_dropout_prob: float = 0.1, hidden_dropout_prob: float = 0.1,
+                 activation_dropout_prob: float = 0.0, layer_norm_eps: float = 1e-12,
+                 pre_norm: bool = False, use_qkv_bias: bool = True, weight_initializer=None,
+                 bias_initializer='zeros', activation: str = 'relu', dtype='float32',
+                 layout='NT'):
+        super().__init__()
+        self._units = units
+        self._hidden_size = hidden_size
+        self._num_heads = num_heads
+        self._attention_dropout_prob = attention_dropout_prob
+        self._hidden_dropout_prob = hidden_dropout_prob
+        self._activation_dropout_prob = activation_dropout_prob
+        self._layer_norm_eps = layer_norm_eps
+        self._pre_norm = pre_norm
+        self._dtype = dtype
+        self._layout = layout
+        self._activation = activation
+        assert layout in ['TN', 'NT'], 'Invalid layout received = {}. ' \
+                                       'Only "TN" and "NT" are accepted!'.format(layout)
+        assert self._units % self._num_heads == 0, 'units must be divisive by the number of heads'
+        self.attn_qkv = Dense(3 * units, in_units=units, use_bias=use_qkv_bias,
+                              weight_initializer=weight_initializer, dtype=dtype)
+        self.attention_proj = Dense(units=units, in_units=units, use_bias=True,
+                                    weight_initializer=weight_initializer, dtype=dtype)
+        attention_layout = 'NTK' if self._layout == 'NT' else 'TNK'
+        self.attention_cell = MultiHeadAttentionCell(
+            query_units=self._units, num_heads=self._num_heads,
+            attention_dropout=self._attention_dropout_prob, scaled=True, dtype=self._dtype,
+            layout=attention_layout)
+        self.layer_norm = LayerNorm(epsilon=layer_norm_eps, in_channels=units, dtype=dtype)
+        self.ffn = PositionwiseFFN(units=units, hidden_size=hidden_size,
+                                   dropout=hidden_dropout_prob,
+                                   activation_dropout=activation_dropout_prob,
+                                   weight_initializer=weight_initializer,
+                                   layer_norm_eps=layer_norm_eps, activation=activation,
+                                   pre_norm=pre_norm, dtype=self._dtype)
+
+    @property
+    def layout(self) -> str:
+        return self._layout
+
+    # ---- C structs -------------------------------------------------------------------------
+    def params_struct(self):
+        p = _lib.EncoderLayerParams()
+        p.qkv_w = T.ptr(self.attn_qkv.weight.data)
+        p.qkv_b = T.ptr(self.attn_qkv.bias.data) if self.attn_qkv.bias is not None else None
+        p.proj_w = T.ptr(self.attention_proj.weight.data)
+        p.proj_b = T.ptr(self.attention_proj.bias.data)
+        p.ln_g = T.ptr(self.layer_norm.gamma.data)
+        p.ln_b = T.ptr(self.layer_norm.beta.data)
+        p.ffn = ffn_params_struct(self.ffn)
+        return p
+
+    def cfg_struct(self, dtype_code):
+        c = _lib.EncoderCfg()
+        c.units, c.hidden, c.heads = self._units, self._hidden_size, self._num_heads
+        c.act = _lib.ACT[self.ffn._act_name]
+        c.pre_norm, c.dtype = int(self._pre_norm), dtype_code
+        c.time_major = int(self._layout == 'TN')
+        c.ln_eps = self._layer_norm_eps
+        return c
+
+    def forward(self, data, attn_mask, *, _need_weights=True, _valid_length=None,
+                _final_seq_mask=False):
+        """data (B, L, C) ['NT'] or (L, B, C) ['TN'], attn_mask (B, L, L)
+        -> (out, attn_weight (B, H, L, L)).  models/transformer.py:234-272.
+
+        One C call launches the whole layer.  ``_need_weights=False`` (used by the stacks when
+        ``output_attention`` is off) returns ``None`` for attn_weight and lets the fused
+        attention kernel run."""
+        x = T.as_tensor(data)
+        m = T.as_tensor(attn_mask)
+        vlt, vlp, vlc = T.valid_length_arg(_valid_length)
+        dev = T.require_device(x, m, vlt, self.attn_qkv.weight.data)
+        x = x.contiguous()
+        if x.dtype != self.attn_qkv.weight.dtype:
+            raise TypeError('data dtype {} != parameter dtype {}'.format(
+                x.dtype, self.attn_qkv.weight.dtype))
+        if self._layout == 'NT':
+            B, L = x.shape[0], x.shape[1]
+        else:
+            L, B = x.shape[0], x.shape[1]
+        mptr = None
+        if m is not None and vlp is None:
+            pred = mask_predicate(m)
+            if pred is not None and tuple(m.shape) == (B, L, L):
+                if pred[0] == 'full':
+                    vlt, vlp, vlc = T.valid_length_arg(pred[1])
+            else:
+                if m.dtype != torch.bool:
+                    m = m != 0
+                m = torch.broadcast_to(m, (B, L, L)).contiguous()
+                mptr = T.ptr(m)
+        out = torch.empty_like(x)
+        w = torch.empty((B, self._num_heads, L, L), dtype=x.dtype, device=dev) \
+            if _need_weights else None
+        cfg = self.cfg_struct(T.code(x))
+        p = self.params_struct()
+        lib = _lib.load()
+        ws = T.workspace(dev, lib.gnlp_encoder_workspace_bytes(ctypes.byref(cfg), B, L,
+                                                               int(_need_weights)))
+        _lib.check(lib.gnlp_encoder_layer_forward(
+            T.ptr(out), T.ptr(x), ctypes.byref(p), ctypes.byref(cfg), B, L, mptr, vlp, vlc,
+            T.ptr(w), int(bool(_final_seq_mask)), T.ptr(ws), 0 if ws is None else ws.numel(),
+            T.stream(dev)))
+        return T.like_caller(out, data), (T.like_caller(w, data) if w is not None else None)
+
+
+def run_encoder_stack(layers, data, valid_length, layout, final_seq_mask, all_encodings=False):
+    """Run a list of post-/pre-norm TransformerEncoderLayers back to back in ONE C call
+    (gnlp_encoder_stack_forward); the mask is the valid_length predicate evaluated in-kernel."""
+    x = T.as_tensor(data)
+    vlt, vlp, vlc = T.valid_length_arg(valid_length)
+    l0 = layers[0]
+    dev = T.require_device(x, vlt, l0.attn_qkv.weight.data)
+    x = x.contiguous()
+    if x.dtype != l0.attn_qkv.weight.dtype:
+        raise TypeError('data dtype {} != parameter dtype {}'.format(x.dtype,
+                                                                     l0.attn_qkv.weight.dtype))
+    if layout == 'NT':
+        B, L = x.shape[0], x.shape[1]
+    else:
+        L, B = x.shape[0], x.shape[1]
+    n = len(layers)
+    cfg = l0.cfg_struct(T.code(x))
+    arr = (_lib.EncoderLayerParams * n)(*[ly.params_struct() for ly in layers])
+    lib = _lib.load()
+    ws = T.workspace(dev, lib.gnlp_encoder_workspace_bytes(ctypes.byref(cfg), B, L, 0))
+    if all_encodings:
+        outs = [torch.empty_like(x) for _ in range(n)]
+        ptrs = (ctypes.c_void_p * n)(*[T.ptr(o) for o in outs])
+        out_ptr = None
+    else:
+        outs = torch.empty_like(x)
+        ptrs = None
+        out_ptr = T.ptr(outs)
+    _lib.check(lib.gnlp_encoder_stack_forward(
+        out_ptr, T.ptr(x), arr, n, ctypes.byref(cfg), B, L, vlp, vlc,
+        int(bool(final_seq_mask) and vlp is not None), ptrs, T.ptr(ws),
+        0 if ws is None else ws.numel(), T.stream(dev)))
+    if all_encodings:
+        return [T.like_caller(o, data) for o in outs]
+    return T.like_caller(outs, data)
+
+
+class TransformerEncoder(nn.Module):
+    """models/transformer.py:276-385."""
+
+    def __init__(self, num_layers=6, recurrent=False, units=512, hidden_size=2048, num_heads=8,
+                 activation_dropout=0.0, dropout=0.1, use_qkv_bias=True, attention_dropout=0.1,
+                 layer_norm_eps=1E-5, data_norm=False, pre_norm=False, weight_initializer=None,
+                 bias_initializer='zeros', activation='relu', dtype='float32', layout='NT'):
+        super().__init__()
+        self._dtype = dtype
+        self.num_layers = num_layers
+        self._recurrent = recurrent
+        self._data_norm = data_norm
+        self._pre_norm = pre_norm
+        self._layout = layout
+        assert layout in ['TN', 'NT'], 'Invalid layout received = {}. ' \
+                                       'Only "TN" and "NT" are accepted!'.format(layout)
+        if self._pre_norm:
+            self.ln_final = LayerNorm(epsilon=layer_norm_eps, in_channels=units, dtype=dtype)
+        if self._data_norm:
+            self.ln_data = LayerNorm(epsilon=layer_norm_eps, in_channels=units, dtype=dtype)
+        real_num_layers = 1 if recurrent else num_layers
+        self.layers = nn.ModuleList([
+            TransformerEncoderLayer(units=units, hidden_size=hidden_size, num_heads=num_heads,
+                                    hidden_dropout_prob=dropout,
+                                    attention_dropout_prob=attention_dropout,
+                                    activation_dropout_prob=activation_dropout,
+                                    use_qkv_bias=use_qkv_bias, layer_norm_eps=layer_norm_eps,
+                                    weight_initializer=weight_initializer, pre_norm=pre_norm,
+                                    activation=activation, layout=self._layout, dtype=dtype)
+            for _ in range(real_num_layers)])
+
+    @property
+    def layout(self) -> str:
+        return self._layout
+
+    def forward(self, data, valid_length):
+        """models/transformer.py:346-385."""
+        out = data
+        if self._data_norm:
+            out = self.ln_data(out)
+        seq = [self.layers[0] if self._recurrent else self.layers[i]
+               for i in range(self.num_layers)]
+        out = run_encoder_stack(seq, out, valid_length, self._layout, final_seq_mask=False)
+        if self._pre_norm:
+            out = self.ln_final(out)
+        return out

@@ -1,0 +1,267 @@
+/*
+ * gluonnlp_amd.h -- C ABI of the MI355X-native (gfx950) Transformer-encoder forward path.
+ *
+ * Drop-in boundary for GluonNLP's encoder hot path.  The reference (dmlc/gluon-nlp) has NO
+ * C/FFI boundary of its own: its boundary is the Python call signature of the functions cited
+ * below (paths relative to the reference checkout, src/gluonnlp/...).  Each entry point here is
+ * what a ctypes/cffi binding inside those Python functions would call.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless named *_host; the caller owns all buffers
+ *    (DLPack zero-copy: the Python shim passes DLTensor.data + byte_offset straight through);
+ *  - shapes / strides are in ELEMENTS, int64_t; the innermost dimension is always contiguous;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call is
+ *    asynchronous on that stream and allocates nothing;
+ *  - return value 0 = ok, <0 = error; gnlp_last_error() gives the thread-local message;
+ *  - the library is reentrant per stream and keeps no global state.
+ */
+#ifndef GLUONNLP_AMD_H_
+#define GLUONNLP_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *gnlp_stream_t;
+
+enum { GNLP_OK = 0, GNLP_ERR_ARG = -1, GNLP_ERR_UNSUPPORTED = -2, GNLP_ERR_LAUNCH = -3 };
+
+/* tensor element types of the activation / weight buffers */
+enum { GNLP_F32 = 0, GNLP_BF16 = 1 };
+/* integer element type of valid_length vectors */
+enum { GNLP_I32 = 0, GNLP_I64 = 1 };
+/* attention_cell.py:153,168 */
+enum { GNLP_ATTN_FULL = 0, GNLP_ATTN_CAUSAL = 1 };
+/* layers.py:236-271 get_activation */
+enum {
+  GNLP_ACT_IDENTITY = 0, GNLP_ACT_RELU = 1, GNLP_ACT_GELU_ERF = 2, GNLP_ACT_GELU_TANH = 3,
+  GNLP_ACT_GELU_SIGMOID = 4, GNLP_ACT_SIGMOID = 5, GNLP_ACT_TANH = 6, GNLP_ACT_LEAKY = 7,
+  GNLP_ACT_ELU = 8, GNLP_ACT_SOFTRELU = 9, GNLP_ACT_SOFTSIGN = 10
+};
+/* layers.py:38-77 get_norm_layer */
+enum { GNLP_NORM_LAYER = 0, GNLP_NORM_RMS = 1, GNLP_NORM_NONE = 2 };
+/* how gnlp_dense combines its optional `other` operand with the activated product */
+enum { GNLP_COMBINE_ADD = 0, GNLP_COMBINE_MUL = 1 };
+
+int gnlp_version(void);
+const char *gnlp_last_error(void);
+/* Number of HIP devices visible / name of the current one (diagnostics only). */
+int gnlp_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masks.  Integer/byte work: results are bit-exact with the reference.
+ * ------------------------------------------------------------------------------------------- */
+
+/* gen_self_attn_mask(data, valid_length, dtype, attn_type, layout)   attention_cell.py:40-183
+ * mask: (B, L, L) bytes, 1 = attend.  full: (j < vl[b]) & (i < vl[b]); causal: (j <= i) &
+ * (i < vl[b]).  valid_length may be NULL (no length predicate). */
+int gnlp_gen_self_attn_mask(uint8_t *mask, const void *valid_length, int vl_dtype, int64_t B,
+                            int64_t L, int attn_type, gnlp_stream_t stream);
+
+/* gen_mem_attn_mask(mem, mem_valid_length, data, data_valid_length)  attention_cell.py:186-274
+ * mask: (B, Lq, Lm) bytes: (j < mem_vl[b]) & (i < data_vl[b]); data_valid_length may be NULL. */
+int gnlp_gen_mem_attn_mask(uint8_t *mask, const void *mem_valid_length,
+                           const void *data_valid_length, int vl_dtype, int64_t B, int64_t Lq,
+                           int64_t Lm, gnlp_stream_t stream);
+
+/* npx.sequence_mask(x, valid_length, use_sequence_length=True, axis=time)
+ * as called at models/bert.py:301-303,311-312 and models/electra.py:292-295,303-304.
+ * x/out: (B, L, C) (time_major = 0) or (L, B, C) (time_major = 1); rows with t >= vl[b] become 0.
+ * out may alias x. */
+int gnlp_sequence_mask(void *out, const void *x, const void *valid_length, int vl_dtype, int dtype,
+                       int64_t B, int64_t L, int64_t C, int time_major, gnlp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Softmax / small ops
+ * ------------------------------------------------------------------------------------------- */
+
+/* masked_softmax(att_score, mask, axis=-1, temperature)   attention_cell.py:277-302
+ * masked_logsoftmax(att_score, mask, axis=-1)             attention_cell.py:305-329 (log_mode=1)
+ * scores/out: contiguous, viewed as shape[0..3] with the softmax over shape[3].
+ * mask: bytes, addressed with mask_stride[0..3] (0 = broadcast) or NULL (plain softmax).
+ * out = softmax(where(mask, x, -inf) / temperature) * mask; a fully masked row gives zeros
+ * (log mode: masked positions are -inf).  temperature <= 0 means "none" (1.0). */
+int gnlp_masked_softmax(void *out, const void *scores, int dtype, const uint8_t *mask,
+                        const int64_t mask_stride[4], const int64_t shape[4], float temperature,
+                        int log_mode, gnlp_stream_t stream);
+
+/* l2_normalize(data, axis=-1, eps)   op.py:289-307:  x / (||x||_2 + eps), rows of length d. */
+int gnlp_l2_normalize(void *out, const void *x, int dtype, int64_t rows, int64_t d, float eps,
+                      gnlp_stream_t stream);
+
+/* get_activation(act)(x)   layers.py:236-338 (GELU erf/tanh/sigmoid, relu, ...), n elements. */
+int gnlp_activation(void *out, const void *x, int dtype, int64_t n, int act, gnlp_stream_t stream);
+
+/* nn.LayerNorm / RMSNorm / NoNorm over the last axis   models/transformer.py:217-218,
+ * layers.py:63,81-138,151-181.  y = norm(x [+ residual]) * gamma + beta, statistics in fp32.
+ * residual, beta may be NULL.  If valid_length != NULL the rows are interpreted as (B, L)
+ * (time_major = 0) or (L, B) (time_major = 1) tokens and rows with t >= vl[b] are written as 0
+ * (the npx.sequence_mask of models/bert.py:311-312 fused into the last norm). */
+int gnlp_norm(void *out, const void *x, const void *residual, const void *gamma, const void *beta,
+              int dtype, int kind, float eps, int64_t rows, int64_t C, const void *valid_length,
+              int vl_dtype, int64_t B, int64_t L, int time_major, gnlp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense (nn.Dense(flatten=False): models/transformer.py:193-206, layers.py:590-612)
+ *   out[m, n] = combine( act( sum_k x[m, k] * w[n, k] + bias[n] ), other[m, n] )
+ * x: (M, K) row stride ldx;  w: (N, K) contiguous;  out: (M, N) row stride ldo;
+ * bias (N) and other (M, N, row stride ldother) may be NULL.  combine = ADD gives the fused
+ * residual (models/transformer.py:268, layers.py:644); MUL gives the gated FFN product
+ * (layers.py:636-638).  bf16 uses MFMA bf16 with fp32 accumulation, f32 the exact-fp32 MFMA.
+ * ------------------------------------------------------------------------------------------- */
+int gnlp_dense(void *out, const void *x, const void *w, const void *bias, const void *other,
+               int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
+               int64_t ldo, int64_t ldother, gnlp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * multi_head_dot_attn(query, key, value, mask, edge_scores, dropout, scaled, normalized, eps,
+ *                     query_head_units, layout, use_einsum)      attention_cell.py:332-524
+ * The NKT / NTK / TNK layouts are stride descriptors (no transposes): element (b, h, t, c) of
+ * q lives at q[b*q_stride[0] + h*q_stride[1] + t*q_stride[2] + c], likewise k, v and ctx.
+ * mask: bytes (B, Lq, Lm) addressed with mask_stride[0..2], or NULL.
+ * valid_length: if mask == NULL and valid_length != NULL the predicate (i < vl[b]) & (j < vl[b])
+ *   is evaluated in-kernel (what gen_self_attn_mask 'full' would have produced).
+ * edge_scores: addressed with edge_stride[0..3] over (b, h, i, j) (0 = broadcast) or NULL; it is
+ *   added BEFORE the temperature (attention_cell.py:453-455).
+ * temperature: sqrt(query_head_units) when scaled, 0 / 1 otherwise.
+ * scores_out / weights_out: (B, H, Lq, Lm) contiguous or NULL; scores_out = QK^T + edge_scores
+ *   (not divided by the temperature), weights_out = the softmax (attention_cell.py:524).
+ * When both are NULL and the shape allows it (bf16, dk = dv = 64) the fused MFMA kernel runs and
+ * the (B, H, Lq, Lm) tensor is never formed.  l2-normalisation (normalized=True) is done by the
+ * caller with gnlp_l2_normalize.
+ * workspace: only needed by the unfused path when scores_out or weights_out is NULL
+ *   (gnlp_attn_workspace_bytes); may be NULL otherwise.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t B, H, Lq, Lm, dk, dv;
+  int64_t q_stride[3], k_stride[3], v_stride[3], o_stride[3]; /* (b, h, t) element strides */
+} gnlp_attn_desc;
+
+size_t gnlp_attn_workspace_bytes(const gnlp_attn_desc *d, int dtype, int want_scores,
+                                 int want_weights);
+
+int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, const void *q,
+                             const void *k, const void *v, const gnlp_attn_desc *d, int dtype,
+                             const uint8_t *mask, const int64_t mask_stride[3],
+                             const void *valid_length, int vl_dtype, const void *edge_scores,
+                             const int64_t edge_stride[4], float temperature, void *workspace,
+                             size_t workspace_bytes, gnlp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * T5 relative-position pieces
+ * ------------------------------------------------------------------------------------------- */
+
+/* gen_rel_position(data, layout)   attention_cell.py:611-656: out[i, j] = j - i, int32 (L, L). */
+int gnlp_gen_rel_position(int32_t *out, int64_t L, gnlp_stream_t stream);
+
+/* relative_position_bucket(relative_position, bidirectional, num_buckets, max_distance)
+ * op.py:229-286.  int32 -> int32, n elements, bit-exact with the float32-log formulation. */
+int gnlp_relative_position_bucket(int32_t *out, const int32_t *rel, int64_t n, int bidirectional,
+                                  int num_buckets, int max_distance, gnlp_stream_t stream);
+
+/* BucketPositionalEmbedding.forward   layers.py:519-524: out[i, :] = weight[bucket(rel[i]), :],
+ * weight (num_buckets, units). */
+int gnlp_bucket_embedding(void *out, const void *weight, const int32_t *rel, int dtype, int64_t n,
+                          int64_t units, int bidirectional, int num_buckets, int max_distance,
+                          gnlp_stream_t stream);
+
+/* RelAttentionScoreCell(method='t5').forward(gen_rel_position(...))   attention_cell.py:876-878
+ * fused: out (H, Lq, Lm), out[h, i, j] = weight[bucket(j - i), h]. */
+int gnlp_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq, int64_t Lm,
+                     int bidirectional, int num_buckets, int max_distance, gnlp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole blocks (one C call launches every kernel of the block on `stream`)
+ * ------------------------------------------------------------------------------------------- */
+
+/* PositionwiseFFN.forward   layers.py:619-647 */
+typedef struct {
+  const void *ffn1_w, *ffn1_b;     /* (F, U), (F) */
+  const void *gate_w, *gate_b;     /* gated_ffn_1, NULL unless use_gated_activation */
+  const void *ffn2_w, *ffn2_b;     /* (U, F), (U) */
+  const void *ln_g, *ln_b;         /* layer_norm.gamma / beta (beta may be NULL) */
+} gnlp_ffn_params;
+
+typedef struct {
+  int64_t units, hidden;
+  int act, gated, norm_kind, pre_norm, dtype;
+  float ln_eps;
+} gnlp_ffn_cfg;
+
+size_t gnlp_ffn_workspace_bytes(const gnlp_ffn_cfg *cfg, int64_t rows);
+int gnlp_positionwise_ffn(void *out, const void *x, const gnlp_ffn_params *p,
+                          const gnlp_ffn_cfg *cfg, int64_t rows, const void *valid_length,
+                          int vl_dtype, int64_t B, int64_t L, int time_major, void *workspace,
+                          size_t workspace_bytes, gnlp_stream_t stream);
+
+/* TransformerEncoderLayer.forward(data, attn_mask)   models/transformer.py:234-272 */
+typedef struct {
+  const void *qkv_w, *qkv_b;       /* attn_qkv (3U, U), (3U) or NULL */
+  const void *proj_w, *proj_b;     /* attention_proj (U, U), (U) */
+  const void *ln_g, *ln_b;         /* layer_norm */
+  gnlp_ffn_params ffn;             /* ffn.* */
+} gnlp_encoder_layer_params;
+
+typedef struct {
+  int64_t units, hidden, heads;
+  int act, pre_norm, dtype, time_major; /* time_major: 0 = 'NT' (B, L, U), 1 = 'TN' (L, B, U) */
+  float ln_eps;
+} gnlp_encoder_cfg;
+
+size_t gnlp_encoder_workspace_bytes(const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                                    int want_weights);
+
+/* mask (B, L, L) bytes or NULL; valid_length or NULL (see gnlp_multi_head_dot_attn).
+ * attn_weights_out (B, H, L, L) or NULL.  final_seq_mask != 0 fuses npx.sequence_mask into the
+ * last norm (needs valid_length).  out may not alias x. */
+int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_layer_params *p,
+                               const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                               const uint8_t *mask, const void *valid_length, int vl_dtype,
+                               void *attn_weights_out, int final_seq_mask, void *workspace,
+                               size_t workspace_bytes, gnlp_stream_t stream);
+
+/* BertTransformer / RobertaEncoder / ElectraEncoder / TransformerEncoder (post-norm) .forward
+ * models/bert.py:259-315, roberta.py:171-188, electra.py:249-307, transformer.py:346-385.
+ * Runs n_layers layers back to back; mask is the valid_length predicate.
+ * final_seq_mask: 1 for BERT/ELECTRA (bert.py:311-312), 0 for RoBERTa (roberta.py:184).
+ * all_encodings: NULL, or n_layers pointers receiving every layer's output
+ *   (output_all_encodings; with final_seq_mask each one is masked and fed on, bert.py:300-304). */
+int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_layer_params *layers,
+                               int n_layers, const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                               const void *valid_length, int vl_dtype, int final_seq_mask,
+                               void *const *all_encodings, void *workspace, size_t workspace_bytes,
+                               gnlp_stream_t stream);
+
+/* T5Block.forward (encoder) / T5Encoder.forward   models/t5.py:492-572, 666-711 */
+typedef struct {
+  const void *attn_ln_g, *attn_ln_b;     /* self_attn_layer_norm.gamma / .beta (beta may be NULL) */
+  const void *q_w, *k_w, *v_w, *proj_w;  /* (inner, d_model) x3, (d_model, inner); bias-free */
+  gnlp_ffn_params ffn;                   /* ffn.* (pre-norm RMS, optional gate) */
+} gnlp_t5_block_params;
+
+typedef struct {
+  int64_t d_model, d_kv, d_ff, heads;
+  int gated, dtype, time_major;          /* gated: 0 = relu, 1 = gated-gelu(tanh) */
+  float ln_eps;
+} gnlp_t5_cfg;
+
+size_t gnlp_t5_workspace_bytes(const gnlp_t5_cfg *cfg, int64_t B, int64_t L);
+
+/* position_bias: (H, L, L) from gnlp_t5_rel_bias.  final_ln_g / final_ln_b: final RMSNorm gamma /
+ * beta (final_ln_g == NULL = run the blocks only; beta may be NULL).  The RMSNorm inside the FFN
+ * uses eps 1e-6 whatever cfg->ln_eps says, as the reference does (layers.py:67-68 does not
+ * forward epsilon to RMSNorm). */
+int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params *layers,
+                            int n_layers, const void *final_ln_g, const void *final_ln_b,
+                            const gnlp_t5_cfg *cfg,
+                            int64_t B, int64_t L, const void *valid_length, int vl_dtype,
+                            const void *position_bias, void *workspace, size_t workspace_bytes,
+                            gnlp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLUONNLP_AMD_H_ */

@@ -1,0 +1,406 @@
+"""GPU parity tests (through the C ABI) for attention, PositionwiseFFN, TransformerEncoderLayer,
+the BERT / RoBERTa / ELECTRA / TransformerEncoder stacks and the T5 encoder, against the committed
+golden fixtures (generated from the reference's torch sibling) and the CPU oracle.
+fp32 within 1e-5, bf16 within 2e-2 (max-abs relative); masks / zeros exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref
+from tests.util import (load_params, oracle_params, prep, rel_err, to_dev, to_np, tol)
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+DT = {torch.float32: 'float32', torch.bfloat16: 'bfloat16'}
+
+
+@pytest.fixture(scope='module')
+def nlp():
+    import gluonnlp_amd
+    from gluonnlp_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    return gluonnlp_amd
+
+
+def _sub(g, prefix):
+    n = len(prefix)
+    return {k[n:]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize('H', [1, 2, 3])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_attention_goldens(nlp, H, dtype):
+    """reference tests/test_attention_cell.py:14-151: B=5, Lq=16, Lm=32, d_k=8, d_v=6, random 0/1
+    mask, shared / per-head / no edge scores, all three layouts must agree with the golden."""
+    ac = nlp.attention_cell
+    g = np.load(os.path.join(G, 'attn_h{}.npz'.format(H)))
+    q, k, v, mask = g['q'], g['k'], g['v'], g['mask']
+    t = tol(dtype)
+    for scaled in [True, False]:
+        for ename in ['none', 'share', 'head']:
+            e = None if ename == 'none' else g['e_' + ename]
+            key = 's{}_{}'.format(int(scaled), ename)
+            if dtype == torch.float32:
+                exp_ctx, exp_s, exp_w = g[key + '_ctx'], g[key + '_scores'], g[key + '_w']
+            else:
+                exp_ctx, (exp_s, exp_w) = ref.multi_head_dot_attn(
+                    prep(q, dtype), prep(k, dtype), prep(v, dtype), mask,
+                    None if e is None else prep(e, dtype), scaled=scaled, query_head_units=8)
+            for layout, perm, back in [('NKT', None, None), ('NTK', (0, 2, 1, 3), None),
+                                       ('TNK', (2, 0, 1, 3), (1, 0, 2))]:
+                qq, kk, vv = [to_dev(x if perm is None else np.transpose(x, perm), dtype)
+                              for x in (q, k, v)]
+                cell = ac.MultiHeadAttentionCell(query_units=8 * H, num_heads=H, scaled=scaled,
+                                                 layout=layout)
+                ctx, (scores, w) = cell(qq, kk, vv, torch.tensor(mask, device='cuda'),
+                                        None if e is None else to_dev(e, dtype))
+                ctx = to_np(ctx)
+                if back is not None:
+                    ctx = np.transpose(ctx, back)
+                assert rel_err(ctx, exp_ctx) < t
+                assert rel_err(to_np(scores), exp_s) < t
+                assert rel_err(to_np(w), exp_w) < t
+                wn = to_np(w)
+                for h in range(H):
+                    assert (wn[:, h][mask == 0] == 0).all()   # masked weights are exactly 0
+                assert (ctx[1] == 0).all()                      # fully masked sample
+    ctx, (_, w) = ac.multi_head_dot_attn(to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype),
+                                         query_head_units=8)
+    if dtype == torch.float32:
+        assert rel_err(to_np(ctx), g['nomask_ctx']) < t
+        assert rel_err(to_np(w), g['nomask_w']) < t
+
+
+def test_attention_errors_and_normalized(nlp):
+    ac = nlp.attention_cell
+    q = torch.randn(2, 2, 4, 8, device='cuda')
+    with pytest.raises(NotImplementedError):
+        ac.multi_head_dot_attn(q, q, q, scaled=True, query_head_units=None)
+    with pytest.raises(NotImplementedError):
+        ac.multi_head_dot_attn(q, q, q, scaled=False, layout='KNT')
+    with pytest.raises(AssertionError):
+        ac.MultiHeadAttentionCell(query_units=10, num_heads=3)
+    ctx, (scores, w) = ac.multi_head_dot_attn(q, q, q, scaled=True, normalized=True,
+                                              query_head_units=8, eps=1e-6)
+    qo = to_np(q)
+    ectx, (es, ew) = ref.multi_head_dot_attn(qo, qo, qo, scaled=True, normalized=True,
+                                             query_head_units=8, eps=1e-6)
+    assert rel_err(to_np(ctx), ectx) < 1e-5 and rel_err(to_np(scores), es) < 1e-5
+
+
+@pytest.mark.parametrize('layout', ['NKT', 'NTK', 'TNK'])
+@pytest.mark.parametrize('mode', ['vl', 'dense', 'none', 'bias_vl', 'bias_dense'])
+@pytest.mark.parametrize('Lq,Lm', [(128, 128), (200, 200), (64, 333), (512, 512)])
+def test_fused_attention_bf16_d64(nlp, layout, mode, Lq, Lm):
+    """The fused MFMA kernel (bf16, d = 64) against the float64 oracle on bf16-rounded inputs, and
+    against the unfused path (which also returns scores / weights)."""
+    if mode in ('vl', 'bias_vl') and Lq != Lm:
+        pytest.skip('valid_length predicate is a self-attention mask')
+    ac = nlp.attention_cell
+    rng = np.random.default_rng(Lq * 7 + Lm)
+    B, H, d = 3, 2, 64
+    q = rng.standard_normal((B, H, Lq, d))
+    k = rng.standard_normal((B, H, Lm, d))
+    v = rng.standard_normal((B, H, Lm, d))
+    # spike one key against one query so that the running max jumps late (online-softmax rescale)
+    k[0, 0, Lm - 3] = q[0, 0, 5] * 3.0
+    vl = np.array([Lm, 1, max(2, Lm * 3 // 5)])
+    mask = None
+    kw = {}
+    if mode in ('vl', 'bias_vl'):
+        mask_np = ref.gen_self_attn_mask((B, Lq), vl)
+        data = torch.zeros((B, Lq, 1), device='cuda')
+        mask = ac.gen_self_attn_mask(data, torch.tensor(vl, device='cuda'))   # tagged -> predicate
+    elif mode in ('dense', 'bias_dense'):
+        mask_np = rng.integers(0, 2, size=(B, Lq, Lm)).astype(bool)
+        mask_np[0, 3, :] = False
+        mask_np[2, :, Lm // 2:] = False
+        mask = torch.tensor(mask_np, device='cuda')
+    else:
+        mask_np = None
+    e = rng.standard_normal((H, Lq, Lm)) if mode.startswith('bias') else None
+    perm = {'NKT': None, 'NTK': (0, 2, 1, 3), 'TNK': (2, 0, 1, 3)}[layout]
+    qq, kk, vv = [to_dev(x if perm is None else np.transpose(x, perm), torch.bfloat16)
+                  for x in (q, k, v)]
+    ed = None if e is None else to_dev(e, torch.bfloat16)
+    ctx, (s_, w_) = ac.multi_head_dot_attn(qq, kk, vv, mask, ed, query_head_units=d, layout=layout,
+                                           _need_scores=False, _need_weights=False)
+    assert s_ is None and w_ is None
+    ectx, _ = ref.multi_head_dot_attn(prep(q, torch.bfloat16), prep(k, torch.bfloat16),
+                                      prep(v, torch.bfloat16), mask_np,
+                                      None if e is None else prep(e, torch.bfloat16),
+                                      query_head_units=d)
+    got = to_np(ctx)
+    if layout == 'TNK':
+        got = np.transpose(got, (1, 0, 2))
+    assert rel_err(got, ectx) < 2e-2
+    if mask_np is not None:
+        dead = ~mask_np.any(-1)                     # fully masked query rows give exact zeros
+        assert (got[dead] == 0).all()
+    ctx2, (s2, w2) = ac.multi_head_dot_attn(qq, kk, vv, mask, ed, query_head_units=d,
+                                            layout=layout)
+    got2 = to_np(ctx2)
+    if layout == 'TNK':
+        got2 = np.transpose(got2, (1, 0, 2))
+    assert rel_err(got2, ectx) < 2e-2
+    assert s2 is not None and w2 is not None
+
+
+def test_fused_attention_from_packed_qkv(nlp):
+    """q / k / v as strided views of one (B, L, 3U) buffer (how the encoder layer calls it)."""
+    ac = nlp.attention_cell
+    rng = np.random.default_rng(8)
+    B, L, H, d = 2, 160, 4, 64
+    U = H * d
+    qkv = rng.standard_normal((B, L, 3 * U))
+    t = to_dev(qkv, torch.bfloat16)
+    q, k, v = [t[..., i * U:(i + 1) * U].reshape(B, L, H, d) for i in range(3)]
+    qo, ko, vo = [prep(qkv[..., i * U:(i + 1) * U].reshape(B, L, H, d), torch.bfloat16)
+                  for i in range(3)]
+    vl = np.array([160, 37])
+    ctx, _ = ac.multi_head_dot_attn(q, k, v, None, None, query_head_units=d, layout='NTK',
+                                    _need_scores=False, _need_weights=False,
+                                    _valid_length=torch.tensor(vl, device='cuda'))
+    ectx, _ = ref.multi_head_dot_attn(qo, ko, vo, ref.gen_self_attn_mask((B, L), vl),
+                                      query_head_units=d, layout='NTK')
+    assert rel_err(to_np(ctx), ectx) < 2e-2
+    assert (to_np(ctx)[1, 37:] == 0).all()
+
+
+# ----------------------------------------------------------------------------- FFN
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('name,kw,okw', [
+    ('postnorm_relu', dict(activation='relu', layer_norm_eps=1e-5), {}),
+    ('postnorm_gelu', dict(activation='gelu', layer_norm_eps=1e-12), {}),
+    ('prenorm_gelu', dict(activation='gelu', pre_norm=True, layer_norm_eps=1e-5), {}),
+    ('gated_gelu_tanh', dict(activation='gelu(tanh)', use_gated_activation=True,
+                             layer_norm_eps=1e-5), {}),
+])
+def test_ffn_goldens(nlp, dtype, name, kw, okw):
+    g = np.load(os.path.join(G, 'ffn.npz'))
+    p = _sub(g, name + '/')
+    ffn = nlp.layers.PositionwiseFFN(units=48, hidden_size=64, dtype=DT[dtype], **kw)
+    load_params(ffn, p, dtype)
+    x = g[name + '_x']
+    got = to_np(ffn(to_dev(x, dtype)))
+    if dtype == torch.float32:
+        exp = g[name + '_y']
+    else:
+        exp = ref.positionwise_ffn(prep(x, dtype), oracle_params(p, dtype),
+                                   activation_name=kw['activation'],
+                                   use_gated_activation=kw.get('use_gated_activation', False),
+                                   layer_norm_eps=kw['layer_norm_eps'],
+                                   pre_norm=kw.get('pre_norm', False))
+    assert rel_err(got, exp) < tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_ffn_rms_nobias_gated(nlp, dtype):
+    """T5-style FFN: pre-norm RMS, no bias, gated gelu(tanh) (layers.py:151-181,636-638)."""
+    rng = np.random.default_rng(12)
+    U, F = 128, 512
+    p = {k[4:]: v for k, v in ref.make_t5_block_params(rng, U, 64, F, 2, True).items()
+         if k.startswith('ffn.')}
+    ffn = nlp.layers.PositionwiseFFN(units=U, hidden_size=F, use_bias=False,
+                                     activation='gelu(tanh)', use_gated_activation=True,
+                                     normalization='rms_norm', pre_norm=True, dtype=DT[dtype],
+                                     center=False, scale=True)
+    load_params(ffn, p, dtype)
+    x = rng.standard_normal((4, 9, U))
+    exp = ref.positionwise_ffn(prep(x, dtype), oracle_params(p, dtype), 'gelu(tanh)', True,
+                               'rms_norm', 1e-6, True)
+    assert rel_err(to_np(ffn(to_dev(x, dtype))), exp) < tol(dtype)
+
+
+# ----------------------------------------------------------------------------- encoder layer / stacks
+CASES = [('enc_tiny_eps1e-12', 48, 64, 2, 1e-12, 'gelu'), ('enc_tiny_eps1e-5', 48, 64, 2, 1e-5, 'gelu'),
+         ('enc_tiny_relu_vl1', 32, 64, 4, 1e-5, 'relu'), ('enc_d64', 128, 512, 2, 1e-12, 'gelu')]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('name,U,F,H,eps,act', CASES)
+def test_encoder_layer_and_stacks(nlp, dtype, name, U, F, H, eps, act):
+    from gluonnlp_amd.models import (BertTransformer, ElectraEncoder, RobertaEncoder,
+                                     TransformerEncoderLayer)
+    ac = nlp.attention_cell
+    g = np.load(os.path.join(G, name + '.npz'))
+    x, vl = g['x'], g['valid_length']
+    B, L = x.shape[:2]
+    t = tol(dtype)
+    lp = [_sub(g, 'L0/'), _sub(g, 'L1/')]
+    if dtype == torch.float32:
+        exp0, expw, exp1, expm = g['out_L0'], g['attn_w_L0'], g['out_L1'], g['out_seqmask']
+    else:
+        op = [oracle_params(p, dtype) for p in lp]
+        xo = prep(x, dtype)
+        exp0, expw = ref.transformer_encoder_layer(xo, ref.gen_self_attn_mask(xo, vl), op[0], H,
+                                                   eps, False, act)
+        exp1, _ = ref.roberta_encoder(xo, vl, op, H, eps, act)
+        expm, _ = ref.bert_transformer(xo, vl, op, H, eps, act)
+    xd = to_dev(x, dtype)
+    vld = torch.tensor(vl, device='cuda')
+    # --- single layer through the reference signature forward(data, attn_mask)
+    layer = TransformerEncoderLayer(units=U, hidden_size=F, num_heads=H, layer_norm_eps=eps,
+                                    activation=act, dtype=DT[dtype])
+    load_params(layer, lp[0], dtype)
+    mask = ac.gen_self_attn_mask(xd, vld)
+    out, w = layer(xd, mask)
+    assert rel_err(to_np(out), exp0) < t
+    assert rel_err(to_np(w), expw) < t
+    # an untagged (dense) copy of the same mask must give the same answer
+    out_d, _ = layer(xd, mask.clone(), _need_weights=False)
+    assert rel_err(to_np(out_d), exp0) < t
+    # --- TN layout == NT transposed (reference tests/test_models_bert.py:51-54)
+    layer_tn = TransformerEncoderLayer(units=U, hidden_size=F, num_heads=H, layer_norm_eps=eps,
+                                       activation=act, dtype=DT[dtype], layout='TN')
+    load_params(layer_tn, lp[0], dtype)
+    xt = xd.transpose(0, 1).contiguous()
+    out_tn, w_tn = layer_tn(xt, ac.gen_self_attn_mask(xt, vld, layout='TN'))
+    assert rel_err(np.swapaxes(to_np(out_tn), 0, 1), exp0) < t
+    assert rel_err(to_np(w_tn), expw) < t
+    # --- stacks
+    for cls, exp, seqm in [(BertTransformer, expm, True), (ElectraEncoder, expm, True),
+                           (RobertaEncoder, exp1, False)]:
+        for layout in ['NT', 'TN']:
+            st = cls(units=U, hidden_size=F, num_layers=2, num_heads=H, layer_norm_eps=eps,
+                     activation=act, dtype=DT[dtype], layout=layout)
+            attr = 'all_encoder_layers' if cls is ElectraEncoder else 'all_layers'
+            for i in range(2):
+                load_params(getattr(st, attr)[i], lp[i], dtype)
+            xin = xd if layout == 'NT' else xt
+            o, extra = st(xin, vld)
+            o = to_np(o)
+            if layout == 'TN':
+                o = np.swapaxes(o, 0, 1)
+            assert extra == []
+            assert rel_err(o, exp) < t
+            if seqm:
+                for b, n in enumerate(vl):
+                    assert (o[b, n:] == 0).all()       # exact zeros beyond valid_length
+    # output_attention / output_all_encodings
+    st = BertTransformer(units=U, hidden_size=F, num_layers=2, num_heads=H, layer_norm_eps=eps,
+                         activation=act, dtype=DT[dtype], output_attention=True,
+                         output_all_encodings=True)
+    for i in range(2):
+        load_params(st.all_layers[i], lp[i], dtype)
+    enc, att = st(xd, vld)
+    assert len(enc) == 2 and len(att) == 2
+    assert rel_err(to_np(enc[1]), expm) < t
+    assert rel_err(to_np(att[0]), expw) < t
+    st2 = BertTransformer(units=U, hidden_size=F, num_layers=2, num_heads=H, layer_norm_eps=eps,
+                          activation=act, dtype=DT[dtype], output_all_encodings=True)
+    for i in range(2):
+        load_params(st2.all_layers[i], lp[i], dtype)
+    enc2, _ = st2(xd, vld)
+    assert rel_err(to_np(enc2[1]), expm) < t
+    assert rel_err(to_np(enc2[0]), ref.sequence_mask(np.asarray(exp0), vl, 1)) < t
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('pre_norm', [False, True])
+def test_transformer_encoder(nlp, dtype, pre_norm):
+    """reference tests/test_models_transformer.py:18-57: units=32, hidden=64, 4 heads, B=8, L=20,
+    valid_length in [1, 20); pre_norm follows the MX text (normalised residual)."""
+    from gluonnlp_amd.models import TransformerEncoder
+    rng = np.random.default_rng(31)
+    U, F, H, B, L, NL = 32, 64, 4, 8, 20, 3
+    lp = [ref.make_encoder_layer_params(rng, U, F) for _ in range(NL)]
+    fin = {'gamma': (1 + 0.1 * rng.standard_normal(U)).astype(np.float32),
+           'beta': (0.1 * rng.standard_normal(U)).astype(np.float32)}
+    x = rng.standard_normal((B, L, U))
+    vl = rng.integers(1, L, size=B)
+    enc = TransformerEncoder(num_layers=NL, units=U, hidden_size=F, num_heads=H, pre_norm=pre_norm,
+                             layer_norm_eps=1e-5, activation='relu', dtype=DT[dtype])
+    for i in range(NL):
+        load_params(enc.layers[i], lp[i], dtype)
+    if pre_norm:
+        load_params(enc.ln_final, fin, dtype)
+    enc.cuda()
+    exp = ref.transformer_encoder(prep(x, dtype), vl, [oracle_params(p, dtype) for p in lp], H,
+                                  1e-5, pre_norm, 'relu', 'NT', ln_final=oracle_params(fin, dtype))
+    got = to_np(enc(to_dev(x, dtype), torch.tensor(vl, device='cuda')))
+    valid = np.arange(L)[None, :] < vl[:, None]
+    assert rel_err(got[valid], exp[valid]) < tol(dtype)
+
+
+def test_padding_invariance_and_large_layer(nlp):
+    """Full-width properties (BERT-large layer shapes, L=512): appending padding leaves the valid
+    outputs unchanged; padded outputs are exactly zero; bf16 stays within 2e-2 of the oracle."""
+    from gluonnlp_amd.models import BertTransformer
+    rng = np.random.default_rng(77)
+    U, F, H, B, L = 1024, 4096, 16, 2, 512
+    lp = [ref.make_encoder_layer_params(rng, U, F)]
+    x = rng.standard_normal((B, L, U)).astype(np.float32)
+    vl = np.array([512, 301])
+    st = BertTransformer(units=U, hidden_size=F, num_layers=1, num_heads=H, dtype='bfloat16')
+    load_params(st.all_layers[0], lp[0], torch.bfloat16)
+    xd = to_dev(x, torch.bfloat16)
+    out, _ = st(xd, torch.tensor(vl, device='cuda'))
+    exp, _ = ref.bert_transformer(prep(x, torch.bfloat16).astype(np.float32), vl,
+                                  [{k: prep(v, torch.bfloat16).astype(np.float32)
+                                    for k, v in lp[0].items()}], H)
+    got = to_np(out)
+    assert rel_err(got, exp) < 2e-2
+    assert (got[1, 301:] == 0).all()
+    x2 = x[:, :384].copy()
+    vl2 = np.array([384, 301])
+    out2, _ = st(to_dev(x2, torch.bfloat16), torch.tensor(vl2, device='cuda'))
+    got2 = to_np(out2)
+    assert rel_err(got2[1, :301], got[1, :301]) < 2e-2
+
+
+# ----------------------------------------------------------------------------- T5
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('act', ['relu', 'gated-gelu'])
+@pytest.mark.parametrize('d_model,d_kv,d_ff,H,B,L', [(128, 64, 512, 4, 3, 96), (32, 8, 64, 4, 3, 12)])
+def test_t5_encoder(nlp, dtype, act, d_model, d_kv, d_ff, H, B, L):
+    """reference tests/test_models_t5.py:19-67 shapes (d_model=128, d_ff=512, H=4, d_kv=64)."""
+    from gluonnlp_amd.models import T5Encoder
+    rng = np.random.default_rng(d_model + L)
+    lp = [ref.make_t5_block_params(rng, d_model, d_kv, d_ff, H, act != 'relu') for _ in range(2)]
+    relw = (rng.standard_normal((32, H)) * d_model ** -0.5).astype(np.float32)
+    fin = {'gamma': (1 + 0.1 * rng.standard_normal(d_model)).astype(np.float32),
+           'beta': np.zeros(d_model, np.float32)}
+    x = rng.standard_normal((B, L, d_model))
+    vl = np.array([L, max(1, L // 3), 1])
+    exp = ref.t5_encoder(prep(x, dtype), vl, prep(relw, dtype),
+                         [oracle_params(p, dtype) for p in lp], oracle_params(fin, dtype), H,
+                         activation_name=act)
+    for layout in ['NT', 'TN']:
+        enc = T5Encoder(d_model, d_kv, d_ff, num_layers=2, num_heads=H, activation=act,
+                        dtype=DT[dtype], layout=layout)
+        for i in range(2):
+            load_params(enc.layers[i], lp[i], dtype)
+        load_params(enc.final_layer_norm, fin, dtype)
+        load_params(enc.relative_position_encoder,
+                    {'_rel_pos_embed.weight': relw}, dtype)
+        enc.cuda()
+        xin = to_dev(x, dtype)
+        if layout == 'TN':
+            xin = xin.transpose(0, 1).contiguous()
+        got = to_np(enc(xin, torch.tensor(vl, device='cuda')))
+        if layout == 'TN':
+            got = np.swapaxes(got, 0, 1)
+        valid = np.arange(L)[None, :] < vl[:, None]
+        assert rel_err(got[valid], exp[valid]) < tol(dtype)
+    # single block through the reference signature (mask tensor + position embeddings)
+    ac = nlp.attention_cell
+    blk = enc.layers[0]
+    blk_nt = type(blk)(d_model, d_kv, d_ff, False, num_heads=H, activation=act, dtype=DT[dtype])
+    load_params(blk_nt, lp[0], dtype)
+    xd = to_dev(x, dtype)
+    pos = enc.relative_position_encoder(ac.gen_rel_position(xd))
+    mask = ac.gen_self_attn_mask(xd, torch.tensor(vl, device='cuda'))
+    pe = ref.rel_attention_score_t5(prep(relw, dtype), ref.gen_rel_position((B, L)))
+    eb = ref.t5_block(prep(x, dtype), ref.gen_self_attn_mask((B, L), vl), pe,
+                      oracle_params(lp[0], dtype), H, activation_name=act)
+    valid = np.arange(L)[None, :] < vl[:, None]
+    gb = to_np(blk_nt(xd, mask, pos))
+    assert rel_err(gb[valid], eb[valid]) < tol(dtype)
+    gb2 = to_np(blk_nt(xd, mask.clone(), pos))          # dense-mask path
+    assert rel_err(gb2[valid], eb[valid]) < tol(dtype)
