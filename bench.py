@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- BERT-large encoder forward (L=512, bf16) sequences/s on N MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torchrun, one
+rank per GPU).  A step = one forward of the 24-layer encoder stack (the hot path of
+BASELINE.json) over one synthetic batch already resident in HBM; with N>1 the batch is sharded
+(weak scaling, B=64 per GPU) and the CLS rows are all-gathered over RCCL each step.
+Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel (the FFN-1
+GEMM+GELU, timed live with HIP events on the launch stream) and the CPU baseline (the numpy
+oracle restatement timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'gluon-nlp_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (kind, units, heads, hidden, layers, L, per-GPU batch, eps)
+    'bert_large': ('bert', 1024, 16, 4096, 24, 512, 64, 1e-12),
+    'bert_base': ('bert', 768, 12, 3072, 12, 128, 256, 1e-12),
+    'electra_large': ('bert', 1024, 16, 4096, 24, 512, 32, 1e-12),
+    'roberta_large': ('roberta', 1024, 16, 4096, 24, 512, 32, 1e-5),
+    't5_base': ('t5', 768, 12, 3072, 12, 1024, 16, 1e-6),
+}
+PEAK = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+def flops_per_seq(U, F, layers, L):
+    # 2 x MACs of the dense contractions, dense over the padded length
+    return layers * L * (8 * U * U + 4 * U * F + 4 * L * U)
+
+
+def build_model(kind, U, H, F, layers, eps, dtype_name, dev):
+    from gluonnlp_amd.models import BertTransformer, RobertaEncoder, T5Encoder
+    torch.manual_seed(0)
+    if kind == 't5':
+        m = T5Encoder(U, 64, F, num_layers=layers, num_heads=H, dtype=dtype_name)
+    elif kind == 'roberta':
+        m = RobertaEncoder(units=U, hidden_size=F, num_layers=layers, num_heads=H,
+                           layer_norm_eps=eps, dtype=dtype_name)
+    else:
+        m = BertTransformer(units=U, hidden_size=F, num_layers=layers, num_heads=H,
+                            layer_norm_eps=eps, dtype=dtype_name)
+    return m.to(dev)
+
+
+def time_dense(M, N, K, act, dtype, dev, iters=20):
+    """Average duration (ms) of the dominant kernel, HIP events on the launch stream."""
+    from gluonnlp_amd.layers import Dense
+    d = Dense(N, K, dtype='bfloat16' if dtype == torch.bfloat16 else 'float32').to(dev)
+    d.bias.data.normal_(0, 0.02)
+    x = torch.randn(M, K, device=dev).to(dtype)
+    out = torch.empty(M, N, device=dev, dtype=dtype)
+    for _ in range(3):
+        d(x, act=act, out=out)
+    torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        d(x, act=act, out=out)
+        ev[i + 1].record()
+    torch.cuda.synchronize(dev)
+    ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(iters)]
+    return float(np.mean(ts))
+
+
+def cpu_baseline(kind, U, H, F, layers, L, eps, sample_b):
+    """The oracle (numpy restatement of the reference's unfused op sequence) in float32 on the
+    host cores, one forward over a bounded sample of the same workload."""
+    from oracle import ref
+    rng = np.random.default_rng(0)
+    lp = [ref.make_encoder_layer_params(rng, U, F, np.float32, random_bias=False)
+          for _ in range(2)]
+    x = rng.standard_normal((sample_b, L, U)).astype(np.float32)
+    vl = np.full(sample_b, L)
+    plist = [lp[i % 2] for i in range(layers)]     # weights alternate: memory stays small
+    t0 = time.perf_counter()
+    ref.bert_transformer(x, vl, plist, H, eps, 'gelu', 'NT',
+                         final_sequence_mask=(kind != 'roberta'))
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get('OMP_NUM_THREADS', '1'))
+    return {'value': sample_b / dt, 'unit': 'sequences/s', 'cores': int(cores), 'kind': 'port',
+            'sample': '1 forward of B={} sequences (L={}, {} layers, fp32 numpy restatement of '
+                      'the reference op sequence; not MXNet), {:.1f} s'.format(sample_b, L, layers,
+                                                                               dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='bert_large', choices=sorted(CONFIGS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: config)')
+    ap.add_argument('--ragged', action='store_true', help='ragged valid_length (reported apart)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist_on = world > 1
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    kind, U, H, F, layers, L, B, eps = CONFIGS[args.config]
+    if args.batch:
+        B = args.batch
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype_name = 'bfloat16' if args.dtype == 'bf16' else 'float32'
+    model = build_model(kind, U, H, F, layers, eps, dtype_name, dev)
+
+    from gluonnlp_amd.parallel import BatchShardedEncoder
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(B, L, U, device=dev, generator=g).to(dtype)
+    if args.ragged:
+        vl = torch.randint(1, L + 1, (B,), device=dev, generator=g)
+        vl[0], vl[-1] = L, 1
+    else:
+        vl = torch.full((B,), L, device=dev, dtype=torch.int64)   # reference harness: full
+    runner = BatchShardedEncoder(model, world_size=world, rank=rank)
+
+    def step():
+        return runner.forward_local(x, vl)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out[0].float()).all()
+
+    if rank == 0:
+        seqs = world * B * args.steps / elapsed
+        fps = flops_per_seq(U, F, layers, L)
+        peak = PEAK[args.dtype]
+        # dominant kernel: FFN-1 GEMM + bias + erf-GELU epilogue (M x F x U), one launch per layer
+        M = B * L
+        act = 'gelu' if kind != 't5' else 'relu'
+        ms = time_dense(M, F, U, act, dtype, dev)
+        kflops = 2.0 * M * F * U
+        achieved = kflops / (ms * 1e-3) / 1e12
+        line = {
+            'metric': 'BERT-large encoder fwd seqs/s L=512' if args.config == 'bert_large'
+                      else '{} encoder fwd seqs/s L={}'.format(args.config, L),
+            'value': seqs, 'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': '{} encoder forward: {} layers, units={}, heads={}, hidden={}, '
+                                   'L={}, B={} per GPU, valid_length={}'.format(
+                                       args.config, layers, U, H, F, L, B,
+                                       'ragged' if args.ragged else 'full'),
+                       'global_batch': world * B, 'seq_len': L,
+                       'parallelism': 'batch-sharded x{} (+ RCCL all_gather of CLS rows)'.format(
+                           world) if dist_on else 'single GPU'},
+            'path_tflops': seqs * fps / 1e12,
+            'path_frac_of_mfma_peak': seqs * fps / 1e12 / (peak * world),
+            'roofline': {'bound': 'mfma', 'kernel': 'dense_{}_kernel (FFN-1 GEMM + bias + {}), '
+                                                    'M={} N={} K={}'.format(args.dtype, act, M, F, U),
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': None,
+                         'avg_launch_ms': ms, 'flops_per_launch': kflops},
+        }
+        if world == 1 and not args.no_cpu_baseline and kind != 't5':
+            line['cpu_baseline'] = cpu_baseline(kind, U, H, F, layers, L, eps, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
