@@ -54,14 +54,28 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(r, x);
 }
 
+// erf-GELU for the bf16 epilogues: x * Phi(x) with Phi(x) ~= sigmoid(x (a1 + a3 x^2 + a5 x^4)),
+// minimax-fitted on [-8, 8]: |gelu error| < 2.6e-5 absolute (bf16 resolution near 1 is 3.9e-3).
+// 7 plain VALU ops + v_exp + v_rcp instead of the ~25 of an erf evaluation.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float kL2E = -1.44269504088896340736f;
+  const float a1 = 1.59501575f * kL2E, a3 = 7.40113036e-02f * kL2E, a5 = -7.03035306e-04f * kL2E;
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float x2 = xc * xc;
+  float t = fmaf(x2, a5, a3);
+  t = fmaf(x2, t, a1);
+  const float e = __builtin_amdgcn_exp2f(xc * t);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
     case GNLP_ACT_IDENTITY: return x;
     case GNLP_ACT_RELU: return fmaxf(x, 0.0f);
     case GNLP_ACT_GELU_ERF: {
-      float e = EXACT ? erff(x * 0.70710678118654752440f) : erf_fast(x * 0.70710678118654752440f);
-      return 0.5f * x * (1.0f + e);
+      if (!EXACT) return gelu_erf_fast(x);
+      return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
     }
     case GNLP_ACT_GELU_TANH: {
       float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);

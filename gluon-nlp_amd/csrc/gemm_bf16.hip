@@ -10,6 +10,8 @@
 // the ds_read address (both sides or neither).  The MFMA is issued as D^T = W_frag . X_frag^T so
 // that each lane ends up with 4 consecutive output columns (8-byte stores, bias as a vector).
 // Blocks are remapped so that each XCD (own L2) walks a contiguous range of tiles.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -20,7 +22,7 @@ struct DenseArgs {
   bf16 *out;
   int64_t M, N, K, ldx, ldo, ldother;
   int act, combine;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, group_m;
 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -41,8 +43,14 @@ dense_bf16_kernel(DenseArgs a) {
   const int bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  // consecutive tiles share the x panel (same tm) and sweep the weight panels
-  const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
+  // grouped order: within a band of GROUP_M row-panels walk m fastest, so the ~32 tiles an XCD
+  // has in flight form a compact patch (few distinct x / weight panels per K-step in its L2)
+  const int GROUP_M = a.group_m;
+  const int band = tile / (GROUP_M * a.tiles_n);
+  const int band_m0 = band * GROUP_M;
+  const int band_h = (a.tiles_m - band_m0) < GROUP_M ? (a.tiles_m - band_m0) : GROUP_M;
+  const int in_band = tile - band * GROUP_M * a.tiles_n;
+  const int tm = band_m0 + in_band % band_h, tn = in_band / band_h;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int lane = threadIdx.x & 63;
@@ -181,6 +189,9 @@ static void launch_act(const DenseArgs &a0, hipStream_t s) {
   DenseArgs a = a0;
   a.tiles_m = (int)((a.M + BM - 1) / BM);
   a.tiles_n = (int)((a.N + BN - 1) / BN);
+  const char *gm = getenv("GNLP_GROUP_M");   // developer knob
+  a.group_m = gm ? atoi(gm) : 8;
+  if (a.group_m < 1) a.group_m = 1;
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
@@ -216,7 +227,13 @@ void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void 
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.ldother = ldother;
   a.act = act; a.combine = combine; a.tiles_m = a.tiles_n = 0;
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-  if (t256 >= 256 && M >= 256 && N >= 256)
+  const char *force = getenv("GNLP_GEMM_TILE");   // developer knob: "128" / "256"
+  const bool big = force ? (force[0] == '2') : (t256 >= 256 && M >= 256 && N >= 256);
+  const char *pp = getenv("GNLP_GEMM_PP");         // developer knob: "0" = plain 2-phase loop
+  if (big && !(pp && pp[0] == '0') &&
+      mfma_bf16_dense_pp_supported(N, ldo, ldother, out, bias, other))
+    launch_mfma_bf16_dense_pp(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
+  else if (big)
     launch_cfg<256, 256, 2, 4>(a, s);
   else
     launch_cfg<128, 128, 2, 2>(a, s);

@@ -1,0 +1,43 @@
+"""Micro-benchmark of gnlp_dense on the BERT-large / BERT-base GEMM shapes (developer tool)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'gluon-nlp_amd'))
+import torch
+from gluonnlp_amd.layers import Dense
+
+def run(M, N, K, act, other, dtype=torch.bfloat16, iters=20):
+    d = Dense(N, K, dtype='bfloat16' if dtype == torch.bfloat16 else 'float32').cuda()
+    d.bias.data.normal_(0, 0.02)
+    x = torch.randn(M, K, device='cuda').to(dtype)
+    o = torch.randn(M, N, device='cuda').to(dtype) if other else None
+    out = torch.empty(M, N, device='cuda', dtype=dtype)
+    for _ in range(3):
+        d(x, act=act, other=o, out=out)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        d(x, act=act, other=o, out=out)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+if __name__ == '__main__':
+    M = int(os.environ.get('M', 32768))
+    shapes = [('qkv', M, 3072, 1024, 'identity', False), ('proj', M, 1024, 1024, 'identity', True),
+              ('ffn1', M, 4096, 1024, 'gelu', False), ('ffn1_noact', M, 4096, 1024, 'identity', False),
+              ('ffn2', M, 1024, 4096, 'identity', True)]
+    knob = os.environ.get('SWEEP', '')
+    vals = os.environ.get('VALS', '').split(',') if knob else ['']
+    for rnd in range(int(os.environ.get('ROUNDS', 2))):
+        for v in vals:
+            if knob:
+                os.environ[knob] = v
+            tot = 0
+            line = []
+            for name, m, n, k, act, other in shapes:
+                ms, tf = run(m, n, k, act, other)
+                if name != 'ffn1_noact': tot += ms
+                line.append('%s %.0fus %.0fTF' % (name, ms * 1e3, tf))
+            print('%s=%s | %s | total %.0f us' % (knob, v, ' | '.join(line), tot * 1e3), flush=True)
