@@ -29,7 +29,7 @@ struct DensePPArgs {
   bf16 *out;
   int64_t M, N, K, ldx, ldo, ldother;
   int combine;
-  int tiles_m, tiles_n, group_m;
+  int tiles_m, tiles_n, group_m, dbg;
 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -201,37 +201,47 @@ dense_bf16_pp_kernel(DensePPArgs a) {
   if (wm == 0) GNLP_BAR();   // balance the stagger barrier
 
   // ---- epilogue ----
-  // A lane holds out[m = fr][n = 4 fq .. +3] of every 16x16 fragment.  v_permlane16_swap between
-  // the fragments of two adjacent m-blocks (i, i+1) turns that into 8 consecutive columns per
-  // lane (even fq: row block i, odd fq: row block i+1), so bias / residual / output move as
-  // 16-byte accesses: 16 stores per lane instead of 32 (the store tail is issue-bound).
+  // The accumulator fragments (lane = one row x 4 columns) go through the now idle LDS so that
+  // every global access is a full 128-byte row segment: each wave owns a private 16 KiB fp32
+  // image [64 rows][64 cols] (16-byte chunk index XOR (row & 15): conflict-free ds_write_b128),
+  // filled and drained twice (rows 0-63, 64-127 of the wave's block).  On the way out a lane
+  // holds 8 consecutive columns of one row: bias is loaded once, residual / gate and the output
+  // move as 16-byte accesses, 8 lanes per 128-byte line.
   const bool has_bias = a.bias != nullptr, has_other = a.other != nullptr;
-  const int odd = fq & 1;
+  char *cw = smem + wave * 16384;
+  const int c8 = lane & 7, rr8 = lane >> 3;
+  const int64_t n = n0 + wn * 64 + c8 * 8;
+  const bool n_ok = n < a.N;            // N % 8 == 0 is guaranteed by the dispatcher
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (has_bias && n_ok) {
+    bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(a.bias + n);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t n = n0 + wn * 64 + j * 16 + (fq >> 1) * 8;
-    const bool n_ok = n < a.N;          // N % 8 == 0 is guaranteed by the dispatcher
-    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (has_bias && n_ok) {
-      bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(a.bias + n);
+    for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
+  }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
-    }
+  for (int p = 0; p < 2; ++p) {
 #pragma unroll
-    for (int ip = 0; ip < 4; ++ip) {
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4 *>(cw + (i * 16 + fr) * 256 + (((j * 4 + fq) ^ fr) << 4)) =
+            acc[j][p * 4 + i];
+    GNLP_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + rr8;
+      const char *rp = cw + row * 256;
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(rp + (((2 * c8) ^ (row & 15)) << 4));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(rp + (((2 * c8 + 1) ^ (row & 15)) << 4));
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[j][2 * ip][e]),
-                                                  __float_as_uint(acc[j][2 * ip + 1][e]), false,
-                                                  false);
-        v[e] = __uint_as_float(r[0]);
-        v[4 + e] = __uint_as_float(r[1]);
+        v[e] = apply_act<false>(lo[e] + bv[e], ACT);
+        v[4 + e] = apply_act<false>(hi[e] + bv[4 + e], ACT);
       }
-      const int64_t m = m0 + wm * 128 + (2 * ip + odd) * 16 + fr;
+      const int64_t m = m0 + wm * 128 + p * 64 + row;
       const bool ok = n_ok && (m < a.M);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = apply_act<false>(v[e] + bv[e], ACT);
       if (has_other && ok) {
         bf16x8 o8 = *reinterpret_cast<const bf16x8 *>(a.other + m * a.ldother + n);
         if (a.combine == GNLP_COMBINE_MUL) {
@@ -245,8 +255,14 @@ dense_bf16_pp_kernel(DensePPArgs a) {
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-      if (ok) *reinterpret_cast<bf16x8 *>(a.out + m * a.ldo + n) = o;
+      if (a.dbg & 1) {   // timing-only build switch: keep the values alive, skip the store
+        asm volatile("" ::"v"(o));
+      } else if (ok) {
+        *reinterpret_cast<bf16x8 *>(a.out + m * a.ldo + n) = o;
+      }
     }
+    GNLP_LGKM0();   // the wave's reads are done before the image is overwritten
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -285,6 +301,8 @@ void launch_mfma_bf16_dense_pp(void *out, const void *x, const void *w, const vo
   const char *gm = getenv("GNLP_GROUP_M");   // developer knob
   a.group_m = gm ? atoi(gm) : 8;
   if (a.group_m < 1) a.group_m = 1;
+  const char *dbg = getenv("GNLP_GEMM_DBG");  // developer knob (timing ablations), default 0
+  a.dbg = dbg ? atoi(dbg) : 0;
   switch (act) {
     case GNLP_ACT_RELU: launch_pp_act<GNLP_ACT_RELU>(a, s); break;
     case GNLP_ACT_GELU_ERF: launch_pp_act<GNLP_ACT_GELU_ERF>(a, s); break;
