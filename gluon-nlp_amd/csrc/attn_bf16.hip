@@ -109,6 +109,8 @@ attn_fwd_bf16_d64(FusedAttn a) {
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.0f;
 
   const bool row_ok = my_q < q_valid;
+  const bool rows_all_ok = __all(row_ok);
+  constexpr float RESCALE_THR = 8.0f;
   const uint8_t *mrow = DENSE_MASK ? a.mask + b * a.ms[0] + qrow * a.ms[1] : nullptr;
   const bf16 *brow = HAS_BIAS ? (const bf16 *)a.bias + b * a.bs[0] + h * a.bs[1] + qrow * a.bs[2]
                               : nullptr;
@@ -136,57 +138,89 @@ attn_fwd_bf16_d64(FusedAttn a) {
     }
 
     // ---- bias, mask, online softmax (one query row per lane, keys split with lane^32) ----
+    // Scores stay in raw units; the temperature is folded into the exp2 argument
+    // (p = exp2(s*c - m)).  The running max is only raised -- and O / l rescaled -- when some row of
+    // the wave grew by more than RESCALE_THR (log2 units), so that most tiles skip the O-wide
+    // multiply; p is then bounded by 2^THR, harmless in bf16 (same relative precision).
     const int64_t kbase_idx = (int64_t)tile * KV_TILE;
-    const bool tail = DENSE_MASK || (kbase_idx + KV_TILE > kv_len);
-    float mloc = NEG_BIG;
+    const bool tail = DENSE_MASK || !rows_all_ok || (kbase_idx + KV_TILE > kv_len);
+    if (HAS_BIAS) {  // host guarantees unit stride, Lm % 4 == 0 and 8-byte alignment
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int64_t j0 = kbase_idx + kb * 32 + g * 8 + hh * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HAS_BIAS) {  // host guarantees unit stride, Lm % 4 == 0 and 8-byte alignment
+        for (int g = 0; g < 4; ++g) {
+          const int64_t j0 = kbase_idx + kb * 32 + g * 8 + hh * 4;
           if (j0 < a.Lm) {
             bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(brow + j0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e];
+            for (int e = 0; e < 4; ++e) sacc[kb][g * 4 + e] += (float)b4[e];
           }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float z = (sacc[kb][g * 4 + e] + bv[e]) * c_scale;
-          if (tail) {
-            bool on = (j0 + e) < kv_len;
-            if (DENSE_MASK && on) on = mrow[(j0 + e) * a.ms[2]] != 0;
-            z = on ? z : NEG_BIG;
-          }
-          sacc[kb][g * 4 + e] = z;
-          mloc = fmaxf(mloc, z);
-        }
-      }
     }
+    if (tail) {   // wave-uniform: only the tile straddling kv_len, dense masks, padded rows
+      const int kv_rem = (int)(kv_len - kbase_idx);   // keys of this tile below kv_len
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int jl = kb * 32 + g * 8 + hh * 4;      // key index inside the tile
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bool on = row_ok && (jl + e) < kv_rem;
+            if (DENSE_MASK && on) on = mrow[(kbase_idx + jl + e) * a.ms[2]] != 0;
+            sacc[kb][g * 4 + e] = on ? sacc[kb][g * 4 + e] : NEG_BIG;
+          }
+        }
+    }
+    float mloc = NEG_BIG;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) mloc = fmaxf(mloc, fmaxf(sacc[kb][e], sacc[kb][e + 1]));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.0f;
-    bf16x8 pf[4];  // B operand fragments of O^T = V^T P^T, k-step s = 2 kb + t
+    const float mz = mloc > -1.0e29f ? mloc * c_scale : NEG_BIG;   // scaled units
+    if (__any(mz > m_run + RESCALE_THR)) {                          // wave-uniform
+      const float m_new = fmaxf(m_run, mz);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float z = sacc[kb][e];
-        float p = __builtin_amdgcn_exp2f(z - m_new);
-        p = (z > -1.0e29f && row_ok) ? p : 0.0f;
-        psum += p;
-        pf[2 * kb + (e >> 3)][e & 7] = (bf16)p;
-      }
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
     }
-    l_run = l_run * alpha + psum;
+    bf16x8 pf[4];  // B operand fragments of O^T = V^T P^T, k-step s = 2 kb + t
+    const f32x2 c2 = {c_scale, c_scale};
+    const f32x2 nm2 = {-m_run, -m_run};
+    f32x2 ps2 = {0.0f, 0.0f};
+    if (tail) {
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+        for (int e = 0; e < 16; e += 2) {
+          const f32x2 s2 = {sacc[kb][e], sacc[kb][e + 1]};
+          const f32x2 t2 = s2 * c2 + nm2;
+          f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+          p2[0] = s2[0] > -1.0e29f ? p2[0] : 0.0f;
+          p2[1] = s2[1] > -1.0e29f ? p2[1] : 0.0f;
+          ps2 += p2;
+          pf[2 * kb + (e >> 3)][e & 7] = (bf16)p2[0];
+          pf[2 * kb + (e >> 3)][(e & 7) + 1] = (bf16)p2[1];
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const f32x2 s2 = {sacc[kb][e], sacc[kb][e + 1]};
+          const f32x2 t2 = s2 * c2 + nm2;
+          const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+          ps2 += p2;
+          pf[2 * kb + (e >> 3)][e & 7] = (bf16)p2[0];
+          pf[2 * kb + (e >> 3)][(e & 7) + 1] = (bf16)p2[1];
+        }
+    }
+    l_run += ps2[0] + ps2[1];
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -204,20 +238,33 @@ attn_fwd_bf16_d64(FusedAttn a) {
     cur ^= 1;
   }
 
-  // ---- finalize: O / l, lane holds ctx[my_q][d*32 + 8 g + 4 hh .. +3] ----
+  // ---- finalize: O / l.  A lane holds ctx[my_q][d*32 + 8 g + 4 hh .. +3]; the wave transposes its
+  // 32 x 64 block through a private 4 KiB LDS image (8-byte slot index XOR (row & 15)) so that the
+  // global stores are full 128-byte rows, 16 bytes per lane.
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-  if (my_q < a.Lq) {
-    bf16 *op = obase + my_q * a.os[2];
+  char *ow = smem + wave * 4096;   // K/V tiles are dead: the loop ended with a barrier
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 o;
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[d][g * 4 + e] * inv_l);
-        *reinterpret_cast<bf16x4 *>(op + d * 32 + g * 8 + hh * 4) = o;
-      }
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[d][g * 4 + e] * inv_l);
+      const int slot = d * 8 + g * 2 + hh;
+      *reinterpret_cast<bf16x4 *>(ow + r * 128 + ((slot ^ (r & 15)) << 3)) = o;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  const int oc = lane & 7, orow0 = lane >> 3;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + orow0;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(ow + row * 128 + (((2 * oc) ^ (row & 15)) << 3));
+    const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(ow + row * 128 + (((2 * oc + 1) ^ (row & 15)) << 3));
+    const bf16x8 o8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    const int64_t qq = q0 + wave * 32 + row;
+    if (qq < a.Lq) *reinterpret_cast<bf16x8 *>(obase + qq * a.os[2] + oc * 8) = o8;
   }
 }
 
@@ -231,14 +278,14 @@ bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv) {
     for (int e = 0; e < 3; ++e)
       if (ss[t][e] % 8 != 0) return false;
   for (int e = 0; e < 3; ++e)
-    if (a.os[e] % 4 != 0) return false;
+    if (a.os[e] % 8 != 0) return false;
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 != 0) return false;
   if (a.bias) {  // vector loads of 4 consecutive keys of the bias row
     if (a.bs[3] != 1 || a.Lm % 4 != 0 || (uintptr_t)a.bias % 8 != 0) return false;
     for (int e = 0; e < 3; ++e)
       if (a.bs[e] % 4 != 0) return false;
   }
-  if ((uintptr_t)a.o % 8 != 0) return false;
+  if ((uintptr_t)a.o % 16 != 0) return false;
   return true;
 }
 
