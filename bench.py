@@ -172,6 +172,14 @@ def main():
         ms = time_dense(M, F, U, act, dtype, dev)
         kflops = 2.0 * M * F * U
         achieved = kflops / (ms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch of the dominant kernel, from the separate PMC passes
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_pmc.json')))
+            for k, v in tj.items():
+                if 'dense_bf16_pp_kernel<2>' in k and args.config == 'bert_large' and act == 'gelu':
+                    traffic = (v['fetch_MB_corrected_x2'] + v['write_MB']) * 1048576.0
+        except Exception:
+            traffic = None
         line = {
             'metric': 'BERT-large encoder fwd seqs/s L=512' if args.config == 'bert_large'
                       else '{} encoder fwd seqs/s L={}'.format(args.config, L),
@@ -191,7 +199,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'dense_{}_kernel (FFN-1 GEMM + bias + {}), '
                                                     'M={} N={} K={}'.format(args.dtype, act, M, F, U),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None,
+                         'frac': achieved / peak, 'traffic': traffic,
                          'avg_launch_ms': ms, 'flops_per_launch': kflops},
         }
         if world == 1 and not args.no_cpu_baseline and kind != 't5':
