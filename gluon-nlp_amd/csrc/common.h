@@ -68,6 +68,24 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {   // two elements, v_pk_* math
+  const float kL2E = -1.44269504088896340736f;
+  const f32x2 a1 = {1.59501575f * kL2E, 1.59501575f * kL2E};
+  const f32x2 a3 = {7.40113036e-02f * kL2E, 7.40113036e-02f * kL2E};
+  const f32x2 a5 = {-7.03035306e-04f * kL2E, -7.03035306e-04f * kL2E};
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -8.0f, 8.0f),
+                    __builtin_amdgcn_fmed3f(x[1], -8.0f, 8.0f)};
+  const f32x2 x2 = xc * xc;
+  f32x2 t = x2 * a5 + a3;
+  t = x2 * t + a1;
+  const f32x2 u = xc * t;
+  const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+  const f32x2 d = one + e;
+  const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return x * r;
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {

@@ -6,15 +6,15 @@
 // Waves 0-3 (upper row half) and waves 4-7 (lower half) share the 4 SIMDs pairwise and run the
 // same program shifted by ONE barrier: while one group issues its ds_read_b128 fragment loads and
 // its direct-to-LDS prefetches, the other group's 16-MFMA cluster owns the matrix pipe.
-// A K-tile (64) is consumed in 4 phases, one 64x32 output quadrant each:
-//   p0: read B-sub0 (4 x b128) + A-sub0 (8)   -> Q(0,0)      stage A0(t+1)
-//   p1: read B-sub1 (4)                        -> Q(0,1)      stage A1(t+1)
-//   p2: read A-sub1 (8)                        -> Q(1,1)      stage B0(t+2)
-//   p3: --                                     -> Q(1,0)      stage B1(t+2), s_waitcnt vmcnt(4)
+// A K-tile (64) is consumed in 2 phases of 32 MFMAs (two 64x32 output quadrants each):
+//   p0: read B-sub0, B-sub1 (8 x b128) + A-sub0 (8) -> Q(0,0), Q(0,1)   stage A0, A1 (t+1)
+//   p1: read A-sub1 (8)                              -> Q(1,1), Q(1,0)   stage B0, B1 (t+2),
+//                                                                        s_waitcnt vmcnt(4)
+// (a 4-phase split with 16-MFMA clusters measured 4 % slower: twice the barriers)
 // LDS = 2 K-tile buffers x {A0, A1, B0, B1} half-tiles of 16 KiB (128 rows x 128 B, 16-byte chunk
 // index XOR ((row>>1)&7), applied on the global SOURCE address and on the ds_read address).
 // Each half-tile is filled by 2 global_load_lds_dwordx4 per lane; a slot is re-staged only after
-// the last ds_read of it has retired behind a barrier (B halves after p1, A halves after p2 of
+// the last ds_read of it has retired behind a barrier (B halves after p0, A halves after p1 of
 // both groups), and a staged slot is read only after the counted vmcnt of EVERY wave followed by a
 // barrier -- prefetches stay in flight across barriers (never vmcnt(0) in the steady state).
 #include <stdlib.h>
@@ -165,36 +165,26 @@ dense_bf16_pp_kernel(DensePPArgs a) {
     char *nb = smem + ((t + 1) & 1) * BUF;
     const bool has1 = (t + 1 < nk), has2 = (t + 2 < nk);
     const int64_t k1 = (int64_t)(t + 1) << 6, k2 = (int64_t)(t + 2) << 6;
-    // ---- phase 0 ----
     read_b(cb, 0);
+    read_b(cb, 1);
     read_a(cb, 0);
-    if (has1) stage_a(nb, 0, k1);
+    if (has1) { stage_a(nb, 0, k1); stage_a(nb, 1, k1); }
     GNLP_LGKM0();
     GNLP_BAR();
     mma(0, 0);
-    GNLP_BAR();
-    // ---- phase 1 ----
-    read_b(cb, 1);
-    if (has1) stage_a(nb, 1, k1);
-    GNLP_LGKM0();
-    GNLP_BAR();
     mma(0, 1);
     GNLP_BAR();
-    // ---- phase 2 ----
     read_a(cb, 1);
-    if (has2) stage_b(cb, 0, k2);
-    GNLP_LGKM0();
-    GNLP_BAR();
-    mma(1, 1);
-    GNLP_BAR();
-    // ---- phase 3 ----
     if (has2) {
+      stage_b(cb, 0, k2);
       stage_b(cb, 1, k2);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    GNLP_LGKM0();
     GNLP_BAR();
+    mma(1, 1);
     mma(1, 0);
     GNLP_BAR();
   }
@@ -235,10 +225,19 @@ dense_bf16_pp_kernel(DensePPArgs a) {
       const f32x4 lo = *reinterpret_cast<const f32x4 *>(rp + (((2 * c8) ^ (row & 15)) << 4));
       const f32x4 hi = *reinterpret_cast<const f32x4 *>(rp + (((2 * c8 + 1) ^ (row & 15)) << 4));
       float v[8];
+      if (ACT == GNLP_ACT_GELU_ERF) {   // packed-math form: 2 elements per VALU instruction
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = apply_act<false>(lo[e] + bv[e], ACT);
-        v[4 + e] = apply_act<false>(hi[e] + bv[4 + e], ACT);
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 g0 = gelu_erf_fast2((f32x2){lo[e] + bv[e], lo[e + 1] + bv[e + 1]});
+          const f32x2 g1 = gelu_erf_fast2((f32x2){hi[e] + bv[4 + e], hi[e + 1] + bv[5 + e]});
+          v[e] = g0[0]; v[e + 1] = g0[1]; v[4 + e] = g1[0]; v[5 + e] = g1[1];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = apply_act<false>(lo[e] + bv[e], ACT);
+          v[4 + e] = apply_act<false>(hi[e] + bv[4 + e], ACT);
+        }
       }
       const int64_t m = m0 + wm * 128 + p * 64 + row;
       const bool ok = n_ok && (m < a.M);

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
                     c_uint8, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgluonnlp_amd.so')
+LIB_PATH = os.environ.get('GNLP_LIB_PATH') or os.path.join(_HERE, 'libgluonnlp_amd.so')
 
 # enums (include/gluonnlp_amd.h)
 F32, BF16 = 0, 1
