@@ -554,9 +554,9 @@ int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_laye
   if (rc) return rc;
   REQUIRE(p && p->qkv_w && p->proj_w && p->ln_g && p->ffn.ffn1_w && p->ffn.ffn2_w && p->ffn.ln_g,
           "missing layer weights");
+  if (B * L == 0) return GNLP_OK;
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype");
   REQUIRE(!final_seq_mask || valid_length, "final_seq_mask needs valid_length");
-  if (B * L == 0) return GNLP_OK;
   REQUIRE(out && x && out != x, "NULL or aliased tensors");
   return encoder_layer_impl(out, x, p, cfg, B, L, mask, valid_length, vl_dtype, attn_weights_out,
                             final_seq_mask, workspace, workspace_bytes, S(stream));
@@ -570,9 +570,9 @@ int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_laye
   int rc = check_encoder_cfg(cfg, B, L);
   if (rc) return rc;
   REQUIRE(layers && n_layers >= 1, "no layers");
+  if (B * L == 0) return GNLP_OK;
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype");
   REQUIRE(!final_seq_mask || valid_length, "final_seq_mask needs valid_length");
-  if (B * L == 0) return GNLP_OK;
   REQUIRE(x && (out || all_encodings), "NULL tensors");
   const size_t act_bytes = align256((size_t)B * L * cfg->units * esize(cfg->dtype));
   const size_t layer_bytes = enc_ws(cfg, B, L, false).total;
