@@ -7,12 +7,15 @@
 // same program shifted by ONE barrier: while one group issues its ds_read_b128 fragment loads and
 // its direct-to-LDS prefetches, the other group's 16-MFMA cluster owns the matrix pipe.
 // A K-tile (64) is consumed in 2 phases of 32 MFMAs (two 64x32 output quadrants each):
-//   p0: read B-sub0, B-sub1 (8 x b128) + A-sub0 (8) -> Q(0,0), Q(0,1)   stage A0, A1 (t+1)
+//   p0: read B-sub0, B-sub1 (8 x b128) + A-sub0 (8) -> Q(0,0), Q(0,1)   stage A0, A1 (t+2)
 //   p1: read A-sub1 (8)                              -> Q(1,1), Q(1,0)   stage B0, B1 (t+2),
-//                                                                        s_waitcnt vmcnt(4)
+//                                                                        s_waitcnt vmcnt(8)
 // (a 4-phase split with 16-MFMA clusters measured 4 % slower: twice the barriers)
-// LDS = 2 K-tile buffers x {A0, A1, B0, B1} half-tiles of 16 KiB (128 rows x 128 B, 16-byte chunk
-// index XOR ((row>>1)&7), applied on the global SOURCE address and on the ds_read address).
+// LDS = 3 A buffers + 2 B buffers of one K-tile each = all 160 KiB; a buffer is two half-tiles of
+// 16 KiB (128 rows x 128 B, 16-byte chunk index XOR ((row>>1)&7), applied on the global SOURCE
+// address and on the ds_read address).  The third A buffer lets BOTH operands of K-tile t+2 be
+// requested during K-tile t, so every direct-to-LDS load has >= 4 barrier intervals (one K-tile of
+// MFMA time) to land before its counted wait; with two A buffers the A halves had 1-2 intervals.
 // Each half-tile is filled by 2 global_load_lds_dwordx4 per lane; a slot is re-staged only after
 // the last ds_read of it has retired behind a barrier (B halves after p0, A halves after p1 of
 // both groups), and a staged slot is read only after the counted vmcnt of EVERY wave followed by a
@@ -47,7 +50,9 @@ template <int ACT>
 __global__ void __launch_bounds__(512)
 dense_bf16_pp_kernel(DensePPArgs a) {
   constexpr int HALF = 128 * 128;        // bytes of one half-tile (128 rows x 64 bf16)
-  constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1
+  constexpr int ABUF = 2 * HALF;         // A0 A1 of one K-tile; 3 of them at offset 0
+  constexpr int BBUF = 2 * HALF;         // B0 B1 of one K-tile; 2 of them behind the A buffers
+  constexpr int BBASE = 3 * ABUF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- XCD-aware, grouped tile mapping (see gemm_bf16.hip) ----
@@ -85,26 +90,25 @@ dense_bf16_pp_kernel(DensePPArgs a) {
       gB[h][t] = a.w + n * a.K + c * 8;
     }
   const int piece_off = wave * 2048;   // two consecutive 1-KiB pieces
-  auto stage_a = [&](char *buf, int h, int64_t k0) {
+  auto stage_a = [&](char *abuf, int h, int64_t k0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       __builtin_amdgcn_global_load_lds((gptr_t)(gA[h][t] + k0),
-                                       (lptr_t)(buf + h * HALF + piece_off + t * 1024), 16, 0, 0);
+                                       (lptr_t)(abuf + h * HALF + piece_off + t * 1024), 16, 0, 0);
   };
-  auto stage_b = [&](char *buf, int h, int64_t k0) {
+  auto stage_b = [&](char *bbuf, int h, int64_t k0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       __builtin_amdgcn_global_load_lds((gptr_t)(gB[h][t] + k0),
-                                       (lptr_t)(buf + (2 + h) * HALF + piece_off + t * 1024), 16,
-                                       0, 0);
+                                       (lptr_t)(bbuf + h * HALF + piece_off + t * 1024), 16, 0, 0);
   };
 
   // ---- fragment read offsets ----
   const int fr = lane & 15, fq = lane >> 4;
   const int sw = (fr >> 1) & 7;
   const int frag_off = fr * 128 + ((fq ^ sw) << 4);
-  const int a_off = wm * HALF + frag_off;                                  // + sub*64 rows
-  const int b_off = (2 + (wn >> 1)) * HALF + (wn & 1) * 64 * 128 + frag_off;  // + sub*32 rows
+  const int a_off = wm * HALF + frag_off;                                   // + sub*64 rows
+  const int b_off = (wn >> 1) * HALF + (wn & 1) * 64 * 128 + frag_off;      // + sub*32 rows
 
   f32x4 acc[4][8];   // [n-frag (2 subs x 2)][m-frag (2 subs x 4)]
 #pragma unroll
@@ -145,15 +149,17 @@ dense_bf16_pp_kernel(DensePPArgs a) {
   };
 
   const int nk = (int)(a.K >> 6);
-  // ---- prologue: K-tile 0 -> buffer 0, B halves of K-tile 1 -> buffer 1 ----
-  stage_b(smem, 0, 0);
-  stage_b(smem, 1, 0);
+  // ---- prologue: K-tiles 0 and 1 ----
   stage_a(smem, 0, 0);
   stage_a(smem, 1, 0);
+  stage_b(smem + BBASE, 0, 0);
+  stage_b(smem + BBASE, 1, 0);
   if (nk > 1) {
-    stage_b(smem + BUF, 0, 64);
-    stage_b(smem + BUF, 1, 64);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    stage_a(smem + ABUF, 0, 64);
+    stage_a(smem + ABUF, 1, 64);
+    stage_b(smem + BBASE + BBUF, 0, 64);
+    stage_b(smem + BBASE + BBUF, 1, 64);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -162,25 +168,27 @@ dense_bf16_pp_kernel(DensePPArgs a) {
   // no stagger 15 % slower), so the late group is the lower row half, waves 4-7.
   if (wm == 1) GNLP_BAR();   // stagger the late group by one barrier
 
+  int ai = 0;   // t % 3
   for (int t = 0; t < nk; ++t) {
-    char *cb = smem + (t & 1) * BUF;
-    char *nb = smem + ((t + 1) & 1) * BUF;
-    const bool has1 = (t + 1 < nk), has2 = (t + 2 < nk);
-    const int64_t k1 = (int64_t)(t + 1) << 6, k2 = (int64_t)(t + 2) << 6;
-    read_b(cb, 0);
-    read_b(cb, 1);
-    read_a(cb, 0);
-    if (has1) { stage_a(nb, 0, k1); stage_a(nb, 1, k1); }
+    char *ca = smem + ai * ABUF;                                   // A of K-tile t
+    char *na = smem + (ai == 0 ? 2 : ai - 1) * ABUF;               // A of K-tile t+2 (= t-1's)
+    char *cbb = smem + BBASE + (t & 1) * BBUF;                     // B of K-tile t and of t+2
+    const bool has2 = (t + 2 < nk);
+    const int64_t k2 = (int64_t)(t + 2) << 6;
+    read_b(cbb, 0);
+    read_b(cbb, 1);
+    read_a(ca, 0);
+    if (has2) { stage_a(na, 0, k2); stage_a(na, 1, k2); }
     GNLP_LGKM0();
     GNLP_BAR();
     mma(0, 0);
     mma(0, 1);
     GNLP_BAR();
-    read_a(cb, 1);
+    read_a(ca, 1);
     if (has2) {
-      stage_b(cb, 0, k2);
-      stage_b(cb, 1, k2);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      stage_b(cbb, 0, k2);
+      stage_b(cbb, 1, k2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile t+1 has landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -189,6 +197,7 @@ dense_bf16_pp_kernel(DensePPArgs a) {
     mma(1, 1);
     mma(1, 0);
     GNLP_BAR();
+    ai = (ai == 2) ? 0 : ai + 1;
   }
   if (wm == 0) GNLP_BAR();   // balance the stagger barrier
 
@@ -278,7 +287,7 @@ bool mfma_bf16_dense_pp_supported(int64_t N, int64_t ldo, int64_t ldother, const
 
 template <int ACT>
 static void launch_pp_act(const DensePPArgs &a, hipStream_t s) {
-  constexpr int LDS = 2 * 4 * 128 * 128;
+  constexpr int LDS = 5 * 2 * 128 * 128;   // 3 A + 2 B K-tile buffers = 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)dense_bf16_pp_kernel<ACT>,
