@@ -221,6 +221,16 @@ dense_bf16_pp_kernel(DensePPArgs a) {
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
+    // residual / gate rows of this pass: all 8 loads in flight before the LDS round trip
+    bf16x8 o8[8];
+    if (has_other) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int64_t m = m0 + wm * 128 + p * 64 + it * 8 + rr8;
+        m = m < a.M ? m : a.M - 1;
+        o8[it] = *reinterpret_cast<const bf16x8 *>(a.other + m * a.ldother + (n_ok ? n : 0));
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -252,14 +262,13 @@ dense_bf16_pp_kernel(DensePPArgs a) {
       }
       const int64_t m = m0 + wm * 128 + p * 64 + row;
       const bool ok = n_ok && (m < a.M);
-      if (has_other && ok) {
-        bf16x8 o8 = *reinterpret_cast<const bf16x8 *>(a.other + m * a.ldother + n);
+      if (has_other) {
         if (a.combine == GNLP_COMBINE_MUL) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= (float)o8[e];
+          for (int e = 0; e < 8; ++e) v[e] *= (float)o8[it][e];
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)o8[e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)o8[it][e];
         }
       }
       bf16x8 o;

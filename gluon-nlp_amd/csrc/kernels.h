@@ -70,6 +70,14 @@ bool mfma_bf16_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int
 void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void *bias,
                             const void *other, int combine, int act, int64_t M, int64_t N,
                             int64_t K, int64_t ldx, int64_t ldo, int64_t ldother, hipStream_t s);
+// Persistent form of the ping-pong kernel (gemm_bf16_ps.hip): M, N multiples of 256, K >= 128.
+bool mfma_bf16_dense_ps_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                                  int64_t ldother, const void *out, const void *bias,
+                                  const void *other);
+void launch_mfma_bf16_dense_ps(void *out, const void *x, const void *w, const void *bias,
+                               const void *other, int combine, int act, int64_t M, int64_t N,
+                               int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
+                               hipStream_t s);
 bool mfma_bf16_dense_pp_supported(int64_t N, int64_t ldo, int64_t ldother, const void *out,
                                   const void *bias, const void *other);
 void launch_mfma_bf16_dense_pp(void *out, const void *x, const void *w, const void *bias,
