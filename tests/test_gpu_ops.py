@@ -265,6 +265,48 @@ def test_dense(nlp, dtype, M, N, K):
     assert rel_err(to_np(nb(xd)), ref.dense(xo, wo)) < t
 
 
+@pytest.mark.parametrize('M,N,K', [
+    (8192, 4096, 192),    # 512 tiles: two per workgroup, tile switch with nk = 3
+    (4608, 4096, 128),    # 288 tiles: workgroups with one and with two tiles, nk = 2 (minimum)
+    (2048, 8192, 320),    # widest N the LDS bias image holds
+    (2048, 8448, 128),    # N > 8192: one-tile-per-workgroup kernel
+])
+def test_dense_persistent(nlp, M, N, K, monkeypatch):
+    """The persistent big-GEMM kernel (csrc/gemm_bf16_ps.hip) against the oracle, and bit for bit
+    against the one-tile-per-workgroup kernel (same accumulation order, same fp32 epilogue)."""
+    from gluonnlp_amd.layers import Dense
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K))
+    w = rng.standard_normal((N, K)) * 0.1
+    b = rng.standard_normal(N)
+    o = rng.standard_normal((M, N))
+    d = Dense(N, K, dtype='bfloat16').cuda()
+    d.weight.data, d.bias.data = to_dev(w, dtype), to_dev(b, dtype)
+    nb = Dense(N, K, use_bias=False, dtype='bfloat16').cuda()
+    nb.weight.data = to_dev(w, dtype)
+    xd, od = to_dev(x, dtype), to_dev(o, dtype)
+    xo, wo, bo, oo = prep(x, dtype), prep(w, dtype), prep(b, dtype), prep(o, dtype)
+    base = ref.dense(xo, wo, bo)
+    t = tol(dtype)
+
+    def variants():
+        return [d(xd), d(xd, act='gelu'), d(xd, act='relu'), d(xd, other=od),
+                d(xd, other=od, combine='mul', act='gelu(tanh)'), nb(xd), nb(xd, other=od)]
+    got = variants()
+    want = [base, ref.activation(base, 'gelu'), ref.activation(base, 'relu'), base + oo,
+            ref.activation(base, 'gelu(tanh)') * oo, ref.dense(xo, wo), ref.dense(xo, wo) + oo]
+    for g, e in zip(got, want):
+        assert rel_err(to_np(g), e) < t
+    monkeypatch.setenv('GNLP_GEMM_PS', '0')
+    for g, h in zip(got, variants()):
+        assert torch.equal(g, h)
+    # a second call on the same buffers gives the same bits (no state left in LDS / scratch)
+    monkeypatch.delenv('GNLP_GEMM_PS')
+    for g, h in zip(got, variants()):
+        assert torch.equal(g, h)
+
+
 def test_dense_mfma_layout_asymmetric(nlp):
     """A = I against an asymmetric B catches transposed fragment maps (exact integer data)."""
     from gluonnlp_amd.layers import Dense
