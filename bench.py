@@ -176,7 +176,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_pmc.json')))
             for k, v in tj.items():
-                if 'dense_bf16_pp_kernel<2>' in k and args.config == 'bert_large' and act == 'gelu':
+                if 'dense_bf16_p' in k and '<2' in k and args.config == 'bert_large' and act == 'gelu':
                     traffic = (v['fetch_MB_corrected_x2'] + v['write_MB']) * 1048576.0
         except Exception:
             traffic = None
