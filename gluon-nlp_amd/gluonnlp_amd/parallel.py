@@ -22,9 +22,11 @@ class BatchShardedEncoder:
     """Wraps an encoder stack (``model(data, valid_length)``) for batch-sharded inference.
 
     ``compute`` may replace the model call (the gloo/CPU tests inject the oracle there); ``group``
-    is the torch.distributed process group (None = default)."""
+    is the torch.distributed process group (None = default); ``force_collective`` issues the
+    all-gather even when ``world_size == 1`` (a one-rank RCCL group exercises the GPU path)."""
 
-    def __init__(self, model=None, world_size=1, rank=0, layout='NT', compute=None, group=None):
+    def __init__(self, model=None, world_size=1, rank=0, layout='NT', compute=None, group=None,
+                 force_collective=False):
         self.model = model
         self.world_size = world_size
         self.rank = rank
@@ -32,6 +34,7 @@ class BatchShardedEncoder:
         self._compute = compute
         self._group = group
         self._side = None
+        self._force = force_collective   # run the gather even with one rank (tests)
 
     # ---- sharding ----------------------------------------------------------------------------
     def shard(self, data, valid_length):
@@ -55,7 +58,7 @@ class BatchShardedEncoder:
         """Encode this rank's shard; all-gather the CLS rows.  -> (out_local, cls_all or cls)."""
         out = self._run(data, valid_length)
         cls = self.cls_rows(out).contiguous()
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._force:
             return out, cls
         import torch.distributed as dist
         n = cls.shape[0]

@@ -404,3 +404,31 @@ def test_t5_encoder(nlp, dtype, act, d_model, d_kv, d_ff, H, B, L):
     assert rel_err(gb[valid], eb[valid]) < tol(dtype)
     gb2 = to_np(blk_nt(xd, mask.clone(), pos))          # dense-mask path
     assert rel_err(gb2[valid], eb[valid]) < tol(dtype)
+
+
+def test_rccl_gather_path_single_rank(nlp, tmp_path):
+    """The N>1 code path of parallel.BatchShardedEncoder (RCCL all_gather_into_tensor of the CLS
+    rows on a side stream) on a one-rank process group: the collective really runs on the GPU."""
+    import torch.distributed as dist
+    from gluonnlp_amd.models import BertTransformer
+    from gluonnlp_amd.parallel import BatchShardedEncoder
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    dist.init_process_group('nccl', init_method='file://' + str(tmp_path / 'rdv'), rank=0,
+                            world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(0)
+        m = BertTransformer(units=128, hidden_size=256, num_layers=2, num_heads=2,
+                            dtype='bfloat16').cuda()
+        x = torch.randn(3, 40, 128, device='cuda').bfloat16()
+        vl = torch.tensor([40, 7, 21], device='cuda')
+        ref_out, ref_cls = BatchShardedEncoder(m).forward_local(x, vl)
+        enc = BatchShardedEncoder(m, world_size=1, rank=0, force_collective=True)
+        for _ in range(3):   # the side stream is reused across steps
+            out, cls_all = enc.forward_local(x, vl)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_out)
+        assert torch.equal(cls_all, ref_cls)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
