@@ -12,9 +12,11 @@
 //
 // Schedule (same ping-pong as gemm_bf16_pp.hip): 8 waves = 2 (M) x 4 (N), each a 128x64 block.
 // Waves w and w+4 share a SIMD and run the same program shifted by ONE barrier.  Per K-tile g:
-//   P0 mem: ds_read B-sub0/1 + A-sub0, stage A(g+1)      [drain rows 64-127 of the previous tile]
+//   P0 mem: ds_read B-sub0/1 + A-sub0, stage A(g+1) rows 64-127 of each half (2 LDS-DMA / wave)
+//                                                        [drain rows 64-127 of the previous tile]
 //   P0 mma: Q(0,0) Q(0,1)                                 (32 MFMA 16x16x32)
-//   P1 mem: ds_read A-sub1, stage B(g+2), counted vmcnt   [drain rows 0-63 if g ends the tile]
+//   P1 mem: ds_read A-sub1, stage A(g+2) rows 0-63 + B(g+2) (6 LDS-DMA / wave), counted vmcnt
+//                                                        [drain rows 0-63 if g ends the tile]
 //   P1 mma: Q(1,1) Q(1,0)
 // The accumulators of rows 0-63 get their last MFMA in P0 of the tile's last K-tile and are first
 // needed again in P0 of the next tile, those of rows 64-127 in P1 / P1: each half has exactly one
@@ -90,30 +92,37 @@ dense_bf16_ps_kernel(DensePSArgs a) {
     n0 = (in_band / band_h) * 256;
   };
 
-  // ---- staging: wave stages pieces 2w, 2w+1 (8 rows each) of every half-tile ----
+  // ---- staging ----
+  // A K-tile is staged in two steps so that both memory phases issue LDS-DMA (each instruction
+  // costs its wave 55-60 cycles, and P0 -- 16 fragment reads -- is the longer phase): rows 0-63 of
+  // each 128-row half ("sub 0", free once both groups have done their P0 reads) in P1 of the
+  // K-tile TWO before, rows 64-127 ("sub 1", free after the P1 reads) in P0 of the K-tile before.
+  // Wave w moves rows 8w..8w+7 of a sub; a B K-tile is moved in one step, pieces 2w, 2w+1.
   const int srow = lane >> 3, cpos = lane & 7;
-  unsigned offA[2], offB[2];   // per-lane byte offsets inside a half-tile panel, tile-invariant
+  unsigned offA, offB[2];   // per-lane byte offsets inside a panel, tile-invariant
+  {
+    const int row = wave * 8 + srow;   // + 64 * sub: same swizzle (64 = 0 mod 16)
+    offA = (unsigned)(row * (int)a.ldx + (cpos ^ ((row >> 1) & 7)) * 8) * 2u;
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int row = (wave * 2 + t) * 8 + srow;
     const int c = cpos ^ ((row >> 1) & 7);
-    offA[t] = (unsigned)(row * (int)a.ldx + c * 8) * 2u;
     offB[t] = (unsigned)(row * a.K + c * 8) * 2u;
   }
   const int piece_off = wave * 2048;   // two consecutive 1-KiB pieces
   const int64_t a_half = 128 * a.ldx, b_half = (int64_t)128 * a.K;   // elements
+  const int64_t a_sub = 64 * a.ldx;
   // (the offsets pass through an empty asm so that "uniform base + lane offset" is formed at the
-  // load -- SGPR-base addressing -- instead of 16 hoisted 64-bit per-lane addresses per tile)
-  auto stage_a = [&](char *buf, const bf16 *base) {   // base: uniform, &x[m0][k0]
-    unsigned o0 = offA[0], o1 = offA[1];
-    asm volatile("" : "+v"(o0), "+v"(o1));
+  // load -- SGPR-base addressing -- instead of hoisted 64-bit per-lane addresses per tile)
+  auto stage_a = [&](char *buf, const bf16 *base, int sub) {   // base: uniform, &x[m0][k0]
+    unsigned o0 = offA;
+    asm volatile("" : "+v"(o0));
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        __builtin_amdgcn_global_load_lds(
-            (gptr_t)((const char *)(base + h * a_half) + (t ? o1 : o0)),
-            (lptr_t)(buf + h * HALF + piece_off + t * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (gptr_t)((const char *)(base + h * a_half + sub * a_sub) + o0),
+          (lptr_t)(buf + h * HALF + sub * 8192 + wave * 1024), 16, 0, 0);
   };
   auto stage_b = [&](char *buf, const bf16 *base) {   // base: uniform, &w[n0][k0]
     unsigned o0 = offB[0], o1 = offB[1];
@@ -207,7 +216,8 @@ dense_bf16_ps_kernel(DensePSArgs a) {
   };
   auto drain = [&](auto Pc, auto Gc, int m0, int n0, DrainIn &d) {
     constexpr int P = decltype(Pc)::value;
-    constexpr int G = decltype(Gc)::value;   // staging loads issued behind drain_loads: 4 or 0
+    constexpr int G = decltype(Gc)::value;   // staging loads issued behind drain_loads: 6, 2, 0
+    static_assert(G == 0 || G == 2 || G == 6, "wait counts are written out for these");
     // The lane-dependent addresses of the drain are recomputed here from an opaque copy of the
     // lane id: hoisted out of the K loop they would hold ~30 VGPRs for the whole kernel.
     int ln = lane;
@@ -222,9 +232,13 @@ dense_bf16_ps_kernel(DensePSArgs a) {
     for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {   // two slabs per LDS round trip
-      if (HAS_OTHER) {
-        if (G == 4)
-          asm volatile("s_waitcnt vmcnt(8)"
+      if (HAS_OTHER) {   // allow the G staging loads + 4 younger rows / stores
+        if (G == 6)
+          asm volatile("s_waitcnt vmcnt(10)"
+                       : "+v"(d.o8[2 * sp][0]), "+v"(d.o8[2 * sp][1]), "+v"(d.o8[2 * sp + 1][0]),
+                         "+v"(d.o8[2 * sp + 1][1])::"memory");
+        else if (G == 2)
+          asm volatile("s_waitcnt vmcnt(6)"
                        : "+v"(d.o8[2 * sp][0]), "+v"(d.o8[2 * sp][1]), "+v"(d.o8[2 * sp + 1][0]),
                          "+v"(d.o8[2 * sp + 1][1])::"memory");
         else
@@ -294,7 +308,8 @@ dense_bf16_ps_kernel(DensePSArgs a) {
   const std::integral_constant<int, 0> P0c;
   const std::integral_constant<int, 1> P1c;
   const std::integral_constant<int, 0> G0c;
-  const std::integral_constant<int, 4> G4c;
+  const std::integral_constant<int, 2> G2c;
+  const std::integral_constant<int, 6> G6c;
 
   const int nk = a.nk;
   int m0c, n0c, m0n = 0, n0n = 0, m0p = 0, n0p = 0;
@@ -315,11 +330,13 @@ dense_bf16_ps_kernel(DensePSArgs a) {
     }
     *reinterpret_cast<bf16x8 *>(smem + BIAS + i * 2) = b8;
   }
-  // ---- prologue: K-tile 0 -> buffer 0, B halves of K-tile 1 -> buffer 1 (nk >= 2) ----
+  // ---- prologue: K-tile 0 -> buffer 0; B and A sub 0 of K-tile 1 -> buffer 1 (nk >= 2) ----
   stage_b(smem, Bc);
-  stage_a(smem, Ac);
+  stage_a(smem, Ac, 0);
+  stage_a(smem, Ac, 1);
   stage_b(smem + BUF, Bc + 64);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  stage_a(smem + BUF, Ac + 64, 0);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   GNLP_LGKM0();   // the bias image
   GNLP_BAR();
   // Waves w and w + 4 share a SIMD, so the late group is the lower row half, waves 4-7.
@@ -331,14 +348,14 @@ dense_bf16_ps_kernel(DensePSArgs a) {
     for (int t = 0; t < nk; ++t) {
       char *cb = smem + par * BUF;
       char *nb = smem + (par ^ 1) * BUF;
-      // ---- P0 ----
+      // ---- P0: fragment reads B-sub0/1 + A-sub0; A(g+1) sub 1 -> other buffer ----
       if (t == 0 && pend) {   // (nk >= 2: K-tile 1 of this tile exists)
         DrainIn din;
         drain_loads(P1c, m0p, n0p, din);
         __builtin_amdgcn_sched_barrier(0);
-        stage_a(nb, Ac + 64);
+        stage_a(nb, Ac + 64, 1);
         __builtin_amdgcn_sched_barrier(0);
-        drain(P1c, G4c, m0p, n0p, din);
+        drain(P1c, G2c, m0p, n0p, din);
         pend = false;
         __builtin_amdgcn_sched_barrier(0);
         read_b(cb, 0);
@@ -349,9 +366,9 @@ dense_bf16_ps_kernel(DensePSArgs a) {
         read_b(cb, 1);
         read_a(cb, 0);
         if (t + 1 < nk) {
-          stage_a(nb, Ac + (int64_t)(t + 1) * 64);
+          stage_a(nb, Ac + (int64_t)(t + 1) * 64, 1);
         } else if (has_next) {
-          stage_a(nb, An);
+          stage_a(nb, An, 1);
         }
       }
       GNLP_LGKM0();
@@ -359,29 +376,33 @@ dense_bf16_ps_kernel(DensePSArgs a) {
       mma(0, 0);
       mma(0, 1);
       GNLP_BAR();
-      // ---- P1 ----
-      // Counted wait: A(g+1) (staged in P0) must have landed, B(g+2) may stay in flight.  vmcnt
-      // retires in issue order, so it is enough to allow as many operations as were issued after
-      // the A(g+1) loads; where the count is not exact it errs towards waiting longer.
+      // ---- P1: fragment reads A-sub1; A(g+2) sub 0 and B(g+2) -> this buffer ----
+      // Counted wait: K-tile g+1 (B from P1 of g-1, A sub 0 likewise, A sub 1 from P0 above) must
+      // have landed, the 6 loads of K-tile g+2 may stay in flight.  vmcnt retires in issue order,
+      // so it is enough to allow as many operations as were issued after the A(g+1) loads; where
+      // the count is not exact it errs towards waiting longer.
       if (t == nk - 1) {
         DrainIn din;
         drain_loads(P0c, m0c, n0c, din);
         __builtin_amdgcn_sched_barrier(0);
-        // B of the next tile's K-tile 1; after the last tile a harmless reload keeps the count
+        // K-tile 1 of the next tile; after the last tile a harmless reload keeps the count
+        stage_a(cb, has_next ? An + 64 : Ac, 0);
         stage_b(cb, has_next ? Bn + 64 : Bc);
         __builtin_amdgcn_sched_barrier(0);
-        drain(P0c, G4c, m0c, n0c, din);   // 8 stores behind the 4 staging loads
+        drain(P0c, G6c, m0c, n0c, din);   // 8 stores behind the 6 staging loads
         __builtin_amdgcn_sched_barrier(0);
         read_a(cb, 1);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
       } else {
         read_a(cb, 1);
         if (t + 2 < nk) {
+          stage_a(cb, Ac + (int64_t)(t + 2) * 64, 0);
           stage_b(cb, Bc + (int64_t)(t + 2) * 64);
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else if (has_next) {
+          stage_a(cb, An, 0);
           stage_b(cb, Bn);
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
