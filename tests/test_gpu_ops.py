@@ -234,8 +234,9 @@ def test_rel_position_and_t5_bias(nlp):
     (8, 64, 48),          # generic VALU path (K % 32 != 0)
     (37, 72, 64),         # MFMA, ragged M and N
     (300, 128, 128),      # MFMA 128x128 tiles
-    (512, 768, 256),      # bf16: 256x256-tile configuration needs >= 256 tiles -> stays 128
+    (512, 768, 256),      # bf16: 256x256-tile configuration needs >= 128 tiles -> stays 128
     (4096, 4096, 128),    # bf16: 256x256 tiles (256 of them)
+    (2304, 4096, 128),    # bf16: 144 tiles of 256x256 on 256 CUs (persistent, one tile each)
     (4100, 4104, 192),    # 256x256 tiles with ragged edges
 ])
 def test_dense(nlp, dtype, M, N, K):
