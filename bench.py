@@ -107,6 +107,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: config)')
     ap.add_argument('--ragged', action='store_true', help='ragged valid_length (reported apart)')
+    ap.add_argument('--from-ids', action='store_true',
+                    help='BERT backbone from token ids: embedding front-end + stack + pooler '
+                         '(SURVEY 8f rank 1; reported apart from the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=4)
     args = ap.parse_args()
@@ -141,6 +144,20 @@ def main():
 
     def step():
         return runner.forward_local(x, vl)
+
+    if args.from_ids:
+        if kind == 't5':
+            raise SystemExit('--from-ids is for the BERT-style backbones')
+        from gluonnlp_amd.models import BertModel
+        torch.manual_seed(0)
+        bm = BertModel(vocab_size=30522, units=U, hidden_size=F, num_layers=layers, num_heads=H,
+                       max_length=max(512, L), layer_norm_eps=eps, dtype=dtype_name).to(dev)
+        ids = torch.randint(0, 30522, (B, L), device=dev, generator=g)
+        tts = torch.zeros_like(ids)
+
+        def step():   # noqa: F811
+            ctx, pooled = bm(ids, tts, vl)
+            return ctx, pooled
 
     for _ in range(args.warmup):
         step()
@@ -181,8 +198,9 @@ def main():
         except Exception:
             traffic = None
         line = {
-            'metric': 'BERT-large encoder fwd seqs/s L=512' if args.config == 'bert_large'
-                      else '{} encoder fwd seqs/s L={}'.format(args.config, L),
+            'metric': ('BERT-large encoder fwd seqs/s L=512' if args.config == 'bert_large'
+                       else '{} encoder fwd seqs/s L={}'.format(args.config, L)) +
+                      (' (token ids -> pooled output)' if args.from_ids else ''),
             'value': seqs, 'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

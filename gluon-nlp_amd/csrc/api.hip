@@ -431,6 +431,30 @@ int gnlp_norm(void *out, const void *x, const void *residual, const void *gamma,
   return check_launch("gnlp_norm");
 }
 
+int gnlp_embedding_forward(void *out, const void *ids, const void *token_types, int id_dtype,
+                           const void *word_w, const void *type_w, const void *pos_w,
+                           const void *ln_gamma, const void *ln_beta, int dtype, float eps,
+                           int64_t B, int64_t L, int64_t units, int64_t vocab_size,
+                           int64_t num_token_types, int64_t max_length, int time_major,
+                           gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(vl_ok(id_dtype), "token ids must be int32 or int64 (got %d)", id_dtype);
+  REQUIRE(B >= 0 && L >= 0 && units >= 0, "negative shape");
+  if (B * L * units == 0) return GNLP_OK;
+  REQUIRE(out && ids && word_w, "NULL tensor");
+  REQUIRE(vocab_size > 0, "vocab_size must be positive");
+  REQUIRE(!type_w || num_token_types > 0, "num_token_types must be positive");
+  REQUIRE(!pos_w || max_length > 0, "max_length must be positive");
+  REQUIRE(!token_types || type_w, "token_types given without a token-type table");
+  REQUIRE(!ln_beta || ln_gamma, "beta given without gamma");
+  const bool ok = launch_embedding(out, ids, token_types, id_dtype, word_w, type_w, pos_w, ln_gamma,
+                                   ln_beta, dtype, eps, B, L, units, time_major, vocab_size,
+                                   num_token_types, max_length, S(stream));
+  REQUIRE(ok, "embedding: units=%lld must be a multiple of %d, <= 2048 (%s), tables 16-byte aligned",
+          (long long)units, dtype == GNLP_BF16 ? 8 : 4, dtype == GNLP_BF16 ? "bf16" : "f32");
+  return check_launch("gnlp_embedding_forward");
+}
+
 int gnlp_dense(void *out, const void *x, const void *w, const void *bias, const void *other,
                int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
                int64_t ldo, int64_t ldother, gnlp_stream_t stream) {

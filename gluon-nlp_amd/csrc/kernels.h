@@ -33,6 +33,13 @@ void launch_bucket_embedding(void *out, const void *weight, const int32_t *rel, 
 void launch_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq,
                         int64_t Lm, const BucketTable &tb, hipStream_t s);
 
+// embed.hip (false: shape / alignment not supported by the vector kernel)
+bool launch_embedding(void *out, const void *ids, const void *types, int id_dtype,
+                      const void *word_w, const void *type_w, const void *pos_w, const void *gamma,
+                      const void *beta, int dtype, float eps, int64_t B, int64_t L, int64_t C,
+                      int time_major, int64_t vocab, int64_t n_types, int64_t max_len,
+                      hipStream_t s);
+
 // norm.hip
 void launch_norm(void *out, const void *x, const void *residual, const void *gamma,
                  const void *beta, int dtype, int kind, float eps, int64_t rows, int64_t C,

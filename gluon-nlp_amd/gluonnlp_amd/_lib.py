@@ -80,6 +80,10 @@ PROTOTYPES = {
     'gnlp_activation': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'gnlp_norm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                           c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
+    'gnlp_embedding_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_float, c_int64,
+                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
+                                       c_void_p]),
     'gnlp_dense': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     'gnlp_attn_workspace_bytes': (c_size_t, [POINTER(AttnDesc), c_int, c_int, c_int]),

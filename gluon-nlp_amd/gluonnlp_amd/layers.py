@@ -14,7 +14,8 @@ from . import _lib
 from . import _tensor as T
 
 __all__ = ['PositionwiseFFN', 'GELU', 'get_activation', 'get_norm_layer', 'RMSNorm', 'NoNorm',
-           'LayerNorm', 'Dense', 'BucketPositionalEmbedding', 'IdentityActivation', 'Activation']
+           'LayerNorm', 'Dense', 'BucketPositionalEmbedding', 'IdentityActivation', 'Activation',
+           'Embedding', 'PositionalEmbedding', 'LearnedPositionalEmbedding', 'embedding_forward']
 
 
 def _empty_param(shape, dtype):
@@ -247,6 +248,89 @@ class Dense(nn.Module):
             _lib.COMBINE_MUL if combine == 'mul' else _lib.COMBINE_ADD, _lib.ACT[act], T.code(xt),
             M, N, K, K, N, N, T.stream(dev)))
         return T.like_caller(out, x)
+
+
+# ------------------------------------------------------------------------------------------
+# Embedding tables of the front-end  (mxnet nn.Embedding; layers.py:370-482)
+# ------------------------------------------------------------------------------------------
+class Embedding(nn.Module):
+    """mxnet.gluon.nn.Embedding(input_dim, output_dim): the table only -- the gather is fused
+    with the other tables and the LayerNorm in ``embedding_forward``."""
+
+    def __init__(self, input_dim, output_dim, weight_initializer=None, dtype='float32'):
+        super().__init__()
+        self._input_dim, self._output_dim = input_dim, output_dim
+        self.weight = _empty_param((input_dim, output_dim), dtype)
+        with torch.no_grad():
+            if callable(weight_initializer):
+                weight_initializer(self.weight.data)
+            else:
+                trunc_norm_(self.weight.data, 0.02)
+
+    def forward(self, ids):
+        return embedding_forward(ids, None, self.weight.data, None, None, None, None, 0.0, 'NT')
+
+
+class LearnedPositionalEmbedding(nn.Module):
+    """layers.py:460-482: a (max_length, units) table read with np.take(mode='clip')."""
+
+    def __init__(self, units, max_length, mode='clip', dtype='float32', weight_initializer=None):
+        super().__init__()
+        if mode != 'clip':
+            raise NotImplementedError('mode={} is not supported'.format(mode))
+        self._units, self._max_length, self._mode = units, max_length, mode
+        self.weight = _empty_param((max_length, units), dtype)
+        with torch.no_grad():
+            if callable(weight_initializer):
+                weight_initializer(self.weight.data)
+            else:
+                trunc_norm_(self.weight.data, 0.02)
+
+
+class PositionalEmbedding(nn.Module):
+    """layers.py:370-401.  Only method='learned' (what BERT / RoBERTa / ELECTRA use) is built;
+    the table lives at ``_embed.weight`` as in the reference."""
+
+    def __init__(self, units, max_length=None, method='sinusoidal', dtype='float32'):
+        super().__init__()
+        if method != 'learned':
+            raise NotImplementedError('method={} is not supported (learned is)'.format(method))
+        self._units, self._max_length, self._method = units, max_length, method
+        self._embed = LearnedPositionalEmbedding(units=units, max_length=max_length, dtype=dtype)
+
+
+def embedding_forward(inputs, token_types, word_w, type_w, pos_w, ln_gamma, ln_beta, eps, layout):
+    """word + token-type + position gathers, add, LayerNorm in one kernel
+    (gnlp_embedding_forward; models/bert.py:458-504)."""
+    ids = T.as_tensor(inputs)
+    tt = T.as_tensor(token_types)
+    dev = T.require_device(ids, tt, word_w, type_w, pos_w, ln_gamma, ln_beta)
+    if ids.dtype not in (torch.int32, torch.int64):
+        raise TypeError('token ids must be int32 or int64, got {}'.format(ids.dtype))
+    if ids.dim() != 2:
+        raise ValueError('inputs must be (batch, time) or (time, batch), got {}'.format(
+            tuple(ids.shape)))
+    ids = ids.contiguous()
+    if tt is not None:
+        if tuple(tt.shape) != tuple(ids.shape):
+            raise ValueError('token_types shape {} != inputs shape {}'.format(tuple(tt.shape),
+                                                                              tuple(ids.shape)))
+        tt = tt.to(ids.dtype).contiguous()
+    if layout == 'NT':
+        B, L = ids.shape
+    elif layout == 'TN':
+        L, B = ids.shape
+    else:
+        raise NotImplementedError('layout={} is not supported'.format(layout))
+    U = word_w.shape[1]
+    out = torch.empty(tuple(ids.shape) + (U,), dtype=word_w.dtype, device=dev)
+    _lib.check(_lib.load().gnlp_embedding_forward(
+        T.ptr(out), T.ptr(ids), T.ptr(tt), _lib.I64 if ids.dtype == torch.int64 else _lib.I32,
+        T.ptr(word_w), T.ptr(type_w), T.ptr(pos_w), T.ptr(ln_gamma), T.ptr(ln_beta),
+        T.code(word_w), float(eps), B, L, U, word_w.shape[0],
+        0 if type_w is None else type_w.shape[0], 0 if pos_w is None else pos_w.shape[0],
+        int(layout == 'TN'), T.stream(dev)))
+    return T.like_caller(out, inputs)
 
 
 # ------------------------------------------------------------------------------------------

@@ -105,6 +105,27 @@ int gnlp_norm(void *out, const void *x, const void *residual, const void *gamma,
               int vl_dtype, int64_t B, int64_t L, int time_major, gnlp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Embedding front-end (the callers either side of the encoder stack):
+ *   BertModel.get_initial_embedding      models/bert.py:458-504
+ *   ElectraModel.get_initial_embedding   models/electra.py:466-510
+ *   RobertaModel.get_initial_embedding   models/roberta.py:337-372
+ *   out[row] = LayerNorm( word_w[ids[row]] + type_w[token_types[row]] + pos_w[t(row)] )
+ * ids / token_types: (B, L) (time_major = 0) or (L, B) (time_major = 1), int32 or int64 (id_dtype);
+ * token_types NULL = all zero (bert.py:490-491); type_w NULL = no token-type table (RoBERTa);
+ * pos_w NULL = pos_embed_type None; positions are arange over the time axis, clipped to
+ * max_length - 1 (LearnedPositionalEmbedding, layers.py:481-482, mode='clip'); ids are clipped to
+ * the table.  ln_gamma NULL = no embedding LayerNorm (RoBERTa encoder_normalize_before=False).
+ * The pooler (apply_pooling, bert.py:506-529: Dense + tanh on the CLS rows) is gnlp_dense with
+ * ldx = the CLS row stride.
+ * ------------------------------------------------------------------------------------------- */
+int gnlp_embedding_forward(void *out, const void *ids, const void *token_types, int id_dtype,
+                           const void *word_w, const void *type_w, const void *pos_w,
+                           const void *ln_gamma, const void *ln_beta, int dtype, float eps,
+                           int64_t B, int64_t L, int64_t units, int64_t vocab_size,
+                           int64_t num_token_types, int64_t max_length, int time_major,
+                           gnlp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense (nn.Dense(flatten=False): models/transformer.py:193-206, layers.py:590-612)
  *   out[m, n] = combine( act( sum_k x[m, k] * w[n, k] + bias[n] ), other[m, n] )
  * x: (M, K) row stride ldx;  w: (N, K) contiguous;  out: (M, N) row stride ldo;

@@ -149,6 +149,27 @@ def test_parameter_names_match_reference():
             'layers.0.ffn.gated_ffn_1.weight', 'layers.0.ffn.ffn_2.weight',
             'layers.0.ffn.layer_norm.gamma'} <= t5
     assert 'layers.0.self_attn_q.bias' not in t5 and 'layers.0.ffn.ffn_1.bias' not in t5
+    # backbones (models/bert.py:376-400, roberta.py:273-313, electra.py:366-397)
+    from gluonnlp_amd.models import BertModel, ElectraModel, RobertaModel
+    kw = dict(vocab_size=20, units=8, hidden_size=16, num_layers=1, num_heads=2, max_length=6)
+    bm = {k for k in BertModel(**kw).state_dict() if not k.startswith('encoder.')}
+    assert bm == {'word_embed.weight', 'token_type_embed.weight', 'token_pos_embed._embed.weight',
+                  'embed_layer_norm.gamma', 'embed_layer_norm.beta', 'pooler.weight',
+                  'pooler.bias'}
+    assert 'encoder.all_layers.0.attn_qkv.weight' in BertModel(**kw).state_dict()
+    rm = {k for k in RobertaModel(classifier_activation=True, **kw).state_dict()
+          if not k.startswith('encoder.')}
+    assert rm == {'word_embed.weight', 'pos_embed._embed.weight', 'embed_ln.gamma',
+                  'embed_ln.beta', 'pooler.weight', 'pooler.bias'}
+    assert not any(k.startswith(('pooler', 'embed_ln')) for k in
+                   RobertaModel(encoder_normalize_before=False, **kw).state_dict())
+    em = {k for k in ElectraModel(embed_size=4, **kw).state_dict() if not k.startswith('encoder.')}
+    assert em == {'word_embed.weight', 'token_type_embed.weight', 'token_pos_embed._embed.weight',
+                  'embed_layer_norm.gamma', 'embed_layer_norm.beta',
+                  'embed_factorized_proj.weight', 'embed_factorized_proj.bias'}
+    assert 'embed_factorized_proj.weight' not in ElectraModel(embed_size=8, **kw).state_dict()
+    with pytest.raises(NotImplementedError):
+        BertModel(pos_embed_type='sinusoidal', **kw)
     m = BertTransformer(units=8, hidden_size=16, num_layers=1, num_heads=2)
     assert m.all_layers[0].attn_qkv.weight.shape == (24, 8)      # (3U, U): Q | K | V thirds
     assert m.all_layers[0].ffn.ffn_1.weight.shape == (16, 8)

@@ -1,0 +1,216 @@
+"""GPU parity tests (through the C ABI) of the embedding front-end and the pooler -- SURVEY 8f
+rank 1: BertModel / RobertaModel / ElectraModel.get_initial_embedding and apply_pooling
+(models/bert.py:458-529, roberta.py:337-398, electra.py:403-510) -- against the CPU oracle.
+fp32 within 1e-5, bf16 within 2e-2; gathers with clipped indices."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref
+from tests.util import load_params, prep, rel_err, to_dev, to_np, tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nlp():
+    import gluonnlp_amd
+    from gluonnlp_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    return gluonnlp_amd
+
+
+def _tables(rng, V, NT, ML, U):
+    word = rng.standard_normal((V, U)) * 0.5
+    typ = rng.standard_normal((NT, U)) * 0.5
+    pos = rng.standard_normal((ML, U)) * 0.5
+    g = 1.0 + 0.1 * rng.standard_normal(U)
+    b = 0.1 * rng.standard_normal(U)
+    return word, typ, pos, g, b
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['NT', 'TN'])
+@pytest.mark.parametrize('id_dtype', [torch.int32, torch.int64])
+def test_embedding_forward(nlp, dtype, layout, id_dtype):
+    from gluonnlp_amd.layers import embedding_forward
+    rng = np.random.default_rng(11)
+    V, NT, ML, U, B, L = 97, 3, 40, 64, 5, 33
+    word, typ, pos, g, b = _tables(rng, V, NT, ML, U)
+    shape = (B, L) if layout == 'NT' else (L, B)
+    ids = rng.integers(0, V, shape)
+    tts = rng.integers(0, NT, shape)
+    d = lambda a: to_dev(a, dtype)
+    o = lambda a: prep(a, dtype)
+    i_d = torch.from_numpy(ids).cuda().to(id_dtype)
+    t_d = torch.from_numpy(tts).cuda().to(id_dtype)
+    t = tol(dtype)
+    # BERT / ELECTRA: three tables + LayerNorm
+    got = embedding_forward(i_d, t_d, d(word), d(typ), d(pos), d(g), d(b), 1e-12, layout)
+    want = ref.initial_embedding(ids, tts, o(word), o(typ), o(pos),
+                                 {'gamma': o(g), 'beta': o(b)}, 1e-12, layout)
+    assert got.shape == shape + (U,) and got.dtype == dtype
+    assert rel_err(to_np(got), want) < t
+    # token_types None == zeros, bit for bit
+    z1 = embedding_forward(i_d, None, d(word), d(typ), d(pos), d(g), d(b), 1e-12, layout)
+    z2 = embedding_forward(i_d, torch.zeros_like(i_d), d(word), d(typ), d(pos), d(g), d(b), 1e-12,
+                           layout)
+    assert torch.equal(z1, z2)
+    # RoBERTa: no token types; with and without the embedding LayerNorm
+    got = embedding_forward(i_d, None, d(word), None, d(pos), d(g), d(b), 1e-5, layout)
+    want = ref.initial_embedding(ids, None, o(word), None, o(pos), {'gamma': o(g), 'beta': o(b)},
+                                 1e-5, layout)
+    assert rel_err(to_np(got), want) < t
+    got = embedding_forward(i_d, None, d(word), None, d(pos), None, None, 0.0, layout)
+    want = ref.initial_embedding(ids, None, o(word), None, o(pos), None, 0.0, layout)
+    assert rel_err(to_np(got), want) < t
+    # a bare gather is exact
+    got = embedding_forward(i_d, None, d(word), None, None, None, None, 0.0, layout)
+    assert torch.equal(got, d(word)[i_d.long()])
+
+
+def test_embedding_clipping_and_errors(nlp):
+    from gluonnlp_amd._lib import GnlpError
+    from gluonnlp_amd.layers import embedding_forward
+    rng = np.random.default_rng(12)
+    V, NT, ML, U = 10, 2, 6, 32
+    word, typ, pos, g, b = _tables(rng, V, NT, ML, U)
+    d = lambda a: to_dev(a, torch.float32)
+    # ids / types out of range and positions beyond max_length are clipped (np.take mode='clip')
+    ids = np.array([[0, 9, 12, -3, 5, 5, 5, 5, 5]])
+    tts = np.array([[0, 1, 7, -1, 0, 0, 0, 0, 1]])
+    got = embedding_forward(torch.from_numpy(ids).cuda(), torch.from_numpy(tts).cuda(), d(word),
+                            d(typ), d(pos), d(g), d(b), 1e-12, 'NT')
+    want = ref.initial_embedding(ids, tts, word, typ, pos, {'gamma': g, 'beta': b}, 1e-12, 'NT')
+    assert rel_err(to_np(got), want) < 1e-5
+    # empty batch
+    e = embedding_forward(torch.zeros((0, 4), dtype=torch.int64, device='cuda'), None, d(word),
+                          None, None, None, None, 0.0, 'NT')
+    assert e.shape == (0, 4, U)
+    with pytest.raises(TypeError):
+        embedding_forward(torch.zeros((2, 2), device='cuda'), None, d(word), None, None, None, None,
+                          0.0, 'NT')
+    with pytest.raises(RuntimeError):
+        embedding_forward(torch.zeros((2, 2), dtype=torch.int64), None, d(word), None, None, None,
+                          None, 0.0, 'NT')
+    with pytest.raises(GnlpError):   # units not a multiple of the vector width
+        embedding_forward(torch.zeros((2, 2), dtype=torch.int64, device='cuda'), None,
+                          d(rng.standard_normal((V, 30))), None, None, None, None, 0.0, 'NT')
+
+
+def _backbone_params(rng, V, NT, ML, U, F, NL, embed=None):
+    E = U if embed is None else embed
+    p = {'word_embed.weight': rng.standard_normal((V, E)) * 0.5,
+         'token_type_embed.weight': rng.standard_normal((NT, E)) * 0.5,
+         'token_pos_embed._embed.weight': rng.standard_normal((ML, E)) * 0.5,
+         'embed_layer_norm.gamma': 1.0 + 0.1 * rng.standard_normal(E),
+         'embed_layer_norm.beta': 0.1 * rng.standard_normal(E)}
+    layers = [ref.make_encoder_layer_params(rng, U, F) for _ in range(NL)]
+    return p, layers
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout,compute_layout', [('NT', 'auto'), ('TN', 'auto'), ('NT', 'TN')])
+def test_bert_model_ids_to_pooled(nlp, dtype, layout, compute_layout):
+    """BertModel.forward (models/bert.py:404-456): ids -> embeddings -> stack -> pooled CLS."""
+    from gluonnlp_amd.models import BertModel
+    rng = np.random.default_rng(21)
+    V, NT, ML, U, F, H, NL, B, L = 120, 2, 48, 64, 128, 4, 2, 4, 24
+    name = 'float32' if dtype == torch.float32 else 'bfloat16'
+    m = BertModel(vocab_size=V, units=U, hidden_size=F, num_layers=NL, num_heads=H, max_length=ML,
+                  num_token_types=NT, dtype=name, layout=layout, compute_layout=compute_layout)
+    p, layers = _backbone_params(rng, V, NT, ML, U, F, NL)
+    p['pooler.weight'] = rng.standard_normal((U, U)) * 0.1
+    p['pooler.bias'] = 0.1 * rng.standard_normal(U)
+    full = dict(p)
+    for i, lp in enumerate(layers):
+        full.update({'encoder.all_layers.{}.{}'.format(i, k): v for k, v in lp.items()})
+    load_params(m, full, dtype)
+    shape = (B, L) if layout == 'NT' else (L, B)
+    ids, tts = rng.integers(0, V, shape), rng.integers(0, NT, shape)
+    vl = np.array([L, 1, 7, L - 3])
+    ctx, pooled = m(torch.from_numpy(ids).cuda(), torch.from_numpy(tts).cuda(),
+                    torch.from_numpy(vl).cuda())
+    o = lambda a: prep(a, dtype)
+    emb = ref.initial_embedding(ids, tts, o(p['word_embed.weight']),
+                                o(p['token_type_embed.weight']),
+                                o(p['token_pos_embed._embed.weight']),
+                                {'gamma': o(p['embed_layer_norm.gamma']),
+                                 'beta': o(p['embed_layer_norm.beta'])}, 1e-12, layout)
+    olayers = [{k: o(v) for k, v in lp.items()} for lp in layers]
+    want_ctx, _ = ref.bert_transformer(emb, vl, olayers, H, 1e-12, 'gelu', layout)
+    want_pool = ref.apply_pooling(want_ctx, o(p['pooler.weight']), o(p['pooler.bias']), 'tanh',
+                                  layout)
+    t = tol(dtype) * (1 if dtype == torch.float32 else 2)   # two layers of bf16 rounding + pooler
+    assert rel_err(to_np(ctx), want_ctx) < t
+    assert rel_err(to_np(pooled), want_pool) < t
+    assert pooled.shape == (B, U)
+    # padded tokens are exactly zero (npx.sequence_mask, bert.py:311-312)
+    c = to_np(ctx) if layout == 'NT' else np.swapaxes(to_np(ctx), 0, 1)
+    for bi in range(B):
+        assert np.all(c[bi, vl[bi]:] == 0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_roberta_and_electra_models(nlp, dtype):
+    from gluonnlp_amd.models import ElectraModel, RobertaModel
+    rng = np.random.default_rng(22)
+    V, NT, ML, U, F, H, NL, B, L, E = 90, 2, 40, 64, 128, 4, 2, 3, 20, 32
+    name = 'float32' if dtype == torch.float32 else 'bfloat16'
+    o = lambda a: prep(a, dtype)
+    t = tol(dtype) * (1 if dtype == torch.float32 else 2)
+    ids, tts = rng.integers(0, V, (B, L)), rng.integers(0, NT, (B, L))
+    vl = np.array([L, 5, 13])
+    dv = lambda a: torch.from_numpy(a).cuda()
+    # ---- RoBERTa: word + position, embed_ln, pooler only with classifier_activation
+    p, layers = _backbone_params(rng, V, NT, ML, U, F, NL)
+    rp = {'word_embed.weight': p['word_embed.weight'],
+          'pos_embed._embed.weight': p['token_pos_embed._embed.weight'],
+          'embed_ln.gamma': p['embed_layer_norm.gamma'], 'embed_ln.beta': p['embed_layer_norm.beta'],
+          'pooler.weight': rng.standard_normal((U, U)) * 0.1,
+          'pooler.bias': 0.1 * rng.standard_normal(U)}
+    full = dict(rp)
+    for i, lp in enumerate(layers):
+        full.update({'encoder.all_layers.{}.{}'.format(i, k): v for k, v in lp.items()})
+    m = RobertaModel(vocab_size=V, units=U, hidden_size=F, num_layers=NL, num_heads=H,
+                     max_length=ML, dtype=name, classifier_activation=True)
+    load_params(m, full, dtype)
+    ctx, pooled = m(dv(ids), dv(vl))
+    emb = ref.initial_embedding(ids, None, o(rp['word_embed.weight']), None,
+                                o(rp['pos_embed._embed.weight']),
+                                {'gamma': o(rp['embed_ln.gamma']), 'beta': o(rp['embed_ln.beta'])},
+                                1e-5)
+    olayers = [{k: o(v) for k, v in lp.items()} for lp in layers]
+    want_ctx, _ = ref.roberta_encoder(emb, vl, olayers, H, 1e-5, 'gelu')
+    assert rel_err(to_np(ctx), want_ctx) < t
+    assert rel_err(to_np(pooled), ref.apply_pooling(want_ctx, o(rp['pooler.weight']),
+                                                    o(rp['pooler.bias']), 'tanh')) < t
+    m2 = RobertaModel(vocab_size=V, units=U, hidden_size=F, num_layers=NL, num_heads=H,
+                      max_length=ML, dtype=name)     # default: pooled = the CLS rows themselves
+    load_params(m2, {k: v for k, v in full.items() if not k.startswith('pooler')}, dtype)
+    ctx2, pooled2 = m2(dv(ids), dv(vl))
+    assert torch.equal(pooled2, ctx2[:, 0, :])
+    # ---- ELECTRA: factorised embedding (embed_size != units), pooled = CLS rows
+    p, layers = _backbone_params(rng, V, NT, ML, U, F, NL, embed=E)
+    p['embed_factorized_proj.weight'] = rng.standard_normal((U, E)) * 0.2
+    p['embed_factorized_proj.bias'] = 0.1 * rng.standard_normal(U)
+    full = dict(p)
+    for i, lp in enumerate(layers):
+        full.update({'encoder.all_encoder_layers.{}.{}'.format(i, k): v for k, v in lp.items()})
+    m = ElectraModel(vocab_size=V, units=U, hidden_size=F, embed_size=E, num_layers=NL,
+                     num_heads=H, max_length=ML, num_token_types=NT, dtype=name)
+    load_params(m, full, dtype)
+    ctx, pooled = m(dv(ids), dv(tts), dv(vl))
+    emb = ref.initial_embedding(ids, tts, o(p['word_embed.weight']),
+                                o(p['token_type_embed.weight']),
+                                o(p['token_pos_embed._embed.weight']),
+                                {'gamma': o(p['embed_layer_norm.gamma']),
+                                 'beta': o(p['embed_layer_norm.beta'])}, 1e-12)
+    if dtype == torch.bfloat16:
+        emb = prep(emb, dtype)      # the device holds the embedding in bf16 before the projection
+    proj = ref.dense(emb, o(p['embed_factorized_proj.weight']), o(p['embed_factorized_proj.bias']))
+    olayers = [{k: o(v) for k, v in lp.items()} for lp in layers]
+    want_ctx, _ = ref.electra_encoder(proj, vl, olayers, H, 1e-12, 'gelu')
+    assert rel_err(to_np(ctx), want_ctx) < t
+    assert torch.equal(pooled, ctx[:, 0, :])

@@ -283,3 +283,48 @@ def test_softmax_and_norm_semantics():
         ref.gelu(x, 'foo')
     with pytest.raises(NotImplementedError):
         ref.norm(x, {}, 'group_norm')
+
+
+@pytest.mark.parametrize('layout', ['NT', 'TN'])
+def test_embedding_front_end_against_torch_ops(layout):
+    """SURVEY 8f rank 1.  The torch sibling has no importable BertModel (its models/bert.py pulls
+    in mxnet), so the restatement of get_initial_embedding / apply_pooling
+    (models/bert.py:458-529) is pinned against the same op sequence written with torch's own CPU
+    ops (F.embedding, F.layer_norm, F.linear + tanh) in float64, plus the properties the reference
+    states: token_types None == zeros, position ids = arange over the time axis broadcast over the
+    batch axis, np.take(mode='clip') beyond max_length."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(7)
+    V, NT, ML, U, B, L = 50, 3, 12, 16, 3, 10
+    word, typ, pos = (rng.standard_normal((n, U)) for n in (V, NT, ML))
+    g, b = rng.standard_normal(U), rng.standard_normal(U)
+    shape = (B, L) if layout == 'NT' else (L, B)
+    ids = rng.integers(0, V, shape)
+    tts = rng.integers(0, NT, shape)
+    got = ref.initial_embedding(ids, tts, word, typ, pos, {'gamma': g, 'beta': b}, 1e-12, layout)
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    e = F.embedding(t(ids), t(word)) + F.embedding(t(tts), t(typ))
+    p = F.embedding(torch.arange(L), t(pos))
+    e = e + (p[None] if layout == 'NT' else p[:, None])
+    want = F.layer_norm(e, (U,), t(g), t(b), 1e-12).numpy()
+    assert np.abs(got - want).max() < 1e-12
+    # token_types None == zeros (bert.py:490-491); no type table / no position table / no LN
+    z = ref.initial_embedding(ids, None, word, typ, pos, {'gamma': g, 'beta': b}, 1e-12, layout)
+    z2 = ref.initial_embedding(ids, np.zeros_like(ids), word, typ, pos, {'gamma': g, 'beta': b},
+                               1e-12, layout)
+    assert np.array_equal(z, z2)
+    assert np.array_equal(ref.initial_embedding(ids, None, word), word[ids])
+    # positions beyond the table are clipped (layers.py:481-482, mode='clip')
+    long_ids = rng.integers(0, V, (2, ML + 5) if layout == 'NT' else (ML + 5, 2))
+    lo = ref.initial_embedding(long_ids, None, word, None, pos, None, 0.0, layout)
+    last = lo[:, -1] if layout == 'NT' else lo[-1]
+    lid = long_ids[:, -1] if layout == 'NT' else long_ids[-1]
+    assert np.allclose(last, word[lid] + pos[ML - 1])
+    # pooler: CLS row -> Dense + tanh
+    seq = rng.standard_normal(shape + (U,))
+    w, bb = rng.standard_normal((U, U)) * 0.2, rng.standard_normal(U)
+    cls = seq[:, 0] if layout == 'NT' else seq[0]
+    assert np.abs(ref.apply_pooling(seq, w, bb, 'tanh', layout) -
+                  torch.tanh(F.linear(t(cls), t(w), t(bb))).numpy()).max() < 1e-12
+    assert np.array_equal(ref.apply_pooling(seq, None, None, 'tanh', layout), cls)
