@@ -217,3 +217,51 @@ def test_persistent_gemm_static_checks(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
     assert ', 0 problems' in r.stdout
+
+
+def test_parameter_files_round_trip(tmp_path):
+    """a Gluon-style ``.params`` file (npz container keyed by the structural
+    parameter names, what MXNet 2.x save_parameters writes) and a torch state_dict both load by
+    name into a model of another dtype; missing / extra / mis-shaped entries raise like Gluon's
+    load_parameters."""
+    from gluonnlp_amd.models import BertModel
+    from gluonnlp_amd.utils import load_parameters, read_parameter_file, save_parameters
+    kw = dict(vocab_size=20, units=8, hidden_size=16, num_layers=1, num_heads=2, max_length=6)
+    torch.manual_seed(3)
+    src = BertModel(**kw)
+    for p in src.parameters():
+        p.data.normal_(0, 0.1)
+    f = str(tmp_path / 'model-0000.params')
+    save_parameters(src, f)
+    got = read_parameter_file(f)
+    assert set(got) == set(dict(src.named_parameters()))
+    dst = load_parameters(BertModel(dtype='bfloat16', **kw), f)
+    for (k, a), (_, b) in zip(src.named_parameters(), dst.named_parameters()):
+        assert b.dtype == torch.bfloat16 and torch.equal(a.data.to(torch.bfloat16), b.data), k
+    # a file written with numpy directly (float16 members are widened)
+    f2 = str(tmp_path / 'half.params')
+    with open(f2, 'wb') as fh:
+        np.savez(fh, **{k: v.numpy().astype(np.float16) for k, v in got.items()})
+    half = load_parameters(BertModel(**kw), f2)
+    assert torch.allclose(half.pooler.weight.data, src.pooler.weight.data, atol=1e-3)
+    # torch state_dict
+    f3 = str(tmp_path / 'model.pt')
+    torch.save(src.state_dict(), f3)
+    dst3 = load_parameters(BertModel(**kw), f3)
+    assert torch.equal(dst3.word_embed.weight.data, src.word_embed.weight.data)
+    # error behaviour of Block.load_parameters
+    part = {k: v for k, v in src.state_dict().items() if not k.startswith('pooler')}
+    f4 = str(tmp_path / 'part.pt')
+    torch.save(part, f4)
+    with pytest.raises(AssertionError):
+        load_parameters(BertModel(**kw), f4)
+    load_parameters(BertModel(**kw), f4, allow_missing=True)
+    with pytest.raises(ValueError):
+        load_parameters(BertModel(use_pooler=False, **kw), f3)
+    load_parameters(BertModel(use_pooler=False, **kw), f3, ignore_extra=True)
+    with pytest.raises(ValueError):
+        load_parameters(BertModel(**dict(kw, units=16, hidden_size=16)), f3)
+    bad = str(tmp_path / 'bad.params')
+    open(bad, 'wb').write(b'\x12\x01\x00\x00 not a parameter file')
+    with pytest.raises(ValueError):
+        read_parameter_file(bad)
