@@ -1,5 +1,7 @@
 """TransformerEncoderLayer / TransformerEncoder -- mirrors the encoder half of
-``gluonnlp/models/transformer.py`` (reference src/gluonnlp/models/transformer.py:136-385)."""
+``gluonnlp/models/transformer.py`` (reference src/gluonnlp/models/transformer.py:136-385) --
+and, composed from the same kernels, the forward of TransformerDecoderLayer /
+TransformerDecoder (:389-598, :738-840).  Incremental decoding is not built."""
 import ctypes
 
 import torch
@@ -7,10 +9,12 @@ from torch import nn
 
 from .. import _lib
 from .. import _tensor as T
-from ..attention_cell import MultiHeadAttentionCell, gen_self_attn_mask, mask_predicate
+from ..attention_cell import (MultiHeadAttentionCell, gen_mem_attn_mask, gen_self_attn_mask,
+                              mask_predicate)
 from ..layers import Dense, LayerNorm, PositionwiseFFN, ffn_params_struct
 
-__all__ = ['TransformerEncoderLayer', 'TransformerEncoder', 'run_encoder_stack']
+__all__ = ['TransformerEncoderLayer', 'TransformerEncoder', 'run_encoder_stack',
+           'TransformerDecoderLayer', 'TransformerDecoder']
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -205,6 +209,151 @@ class TransformerEncoder(nn.Module):
         seq = [self.layers[0] if self._recurrent else self.layers[i]
                for i in range(self.num_layers)]
         out = run_encoder_stack(seq, out, valid_length, self._layout, final_seq_mask=False)
+        if self._pre_norm:
+            out = self.ln_final(out)
+        return out
+
+
+class TransformerDecoderLayer(nn.Module):
+    """models/transformer.py:389-598: causal self-attention, attention over the memory, FFN.
+    Built from the encoder path's kernels: packed-QKV GEMM, the fused attention kernel with a byte
+    mask (causal / memory masks are arbitrary masks to it; Lq != Lm for the memory), projection
+    GEMMs with the residual fused, LayerNorm, PositionwiseFFN."""
+
+    def __init__(self, units: int = 512, mem_units=None, hidden_size: int = 2048,
+                 num_heads: int = 8, activation_dropout: float = 0.0, dropout: float = 0.1,
+                 attention_dropout: float = 0.1, layer_norm_eps: float = 1E-5,
+                 activation: str = 'relu', pre_norm: bool = False, use_qkv_bias: bool = True,
+                 weight_initializer=None, bias_initializer='zeros', dtype='float32', layout='NT'):
+        super().__init__()
+        self._dtype = dtype
+        self._units = units
+        self._mem_units = units if mem_units is None else mem_units
+        self._pre_norm = pre_norm
+        self._num_heads = num_heads
+        self._layout = layout
+        assert layout in ['TN', 'NT'], 'Invalid layout received = {}. ' \
+                                       'Only "TN" and "NT" are accepted!'.format(layout)
+        attention_layout = 'NTK' if layout == 'NT' else 'TNK'
+        if units % num_heads:
+            raise ValueError('In Transformer, units should be divided exactly by the number of '
+                             'heads. Received units={}, num_heads={}'.format(units, num_heads))
+        kw = dict(weight_initializer=weight_initializer, dtype=dtype)
+        self.attn_in_qkv = Dense(3 * units, in_units=units, use_bias=use_qkv_bias, **kw)
+        self.self_attention = MultiHeadAttentionCell(query_units=units, num_heads=num_heads,
+                                                     attention_dropout=attention_dropout,
+                                                     dtype=dtype, layout=attention_layout)
+        self.proj_in = Dense(units=units, in_units=units, use_bias=True, **kw)
+        self.attn_inter_q = Dense(units, in_units=units, use_bias=use_qkv_bias, **kw)
+        self.attn_inter_k = Dense(units, in_units=self._mem_units, use_bias=use_qkv_bias, **kw)
+        self.attn_inter_v = Dense(units, in_units=self._mem_units, use_bias=use_qkv_bias, **kw)
+        self.inter_attention = MultiHeadAttentionCell(query_units=units, num_heads=num_heads,
+                                                      attention_dropout=attention_dropout,
+                                                      dtype=dtype, layout=attention_layout)
+        self.proj_inter = Dense(units=units, in_units=units, use_bias=True, **kw)
+        self.ln_in = LayerNorm(epsilon=layer_norm_eps, in_channels=units, dtype=dtype)
+        self.ln_inter = LayerNorm(epsilon=layer_norm_eps, in_channels=units, dtype=dtype)
+        self.ffn = PositionwiseFFN(units=units, hidden_size=hidden_size, dropout=dropout,
+                                   activation_dropout=activation_dropout,
+                                   weight_initializer=weight_initializer,
+                                   layer_norm_eps=layer_norm_eps, activation=activation,
+                                   pre_norm=pre_norm, dtype=dtype)
+
+    @property
+    def layout(self) -> str:
+        return self._layout
+
+    def _heads(self, x):
+        return x.reshape(x.shape[0], x.shape[1], self._num_heads, -1)
+
+    def forward(self, data, mem, self_causal_mask, mem_attn_mask):
+        """data (B, L, C) / (L, B, C); mem (B, Lm, C_mem) / (Lm, B, C_mem); self_causal_mask
+        (B, L, L); mem_attn_mask (B, L, Lm) -> out like data.  models/transformer.py:513-598
+        (with pre_norm the residual is the NORMALISED input, as the MXNet text has it)."""
+        x = T.as_tensor(data)
+        m = T.as_tensor(mem)
+        if self._pre_norm:
+            x = self.ln_in(x)
+        qkv = T.as_tensor(self.attn_in_qkv(x))
+        U = self._units
+        q, k, v = qkv[..., :U], qkv[..., U:2 * U], qkv[..., 2 * U:]
+        out, _ = self.self_attention(self._heads(q), self._heads(k), self._heads(v),
+                                     self_causal_mask, _need_scores=False, _need_weights=False)
+        out = self.proj_in(out, other=x)            # + data, fused in the GEMM epilogue
+        if not self._pre_norm:
+            out = self.ln_in(out)
+        x = T.as_tensor(out)
+        if self._pre_norm:
+            x = self.ln_inter(x)
+        out, _ = self.inter_attention(self._heads(T.as_tensor(self.attn_inter_q(x))),
+                                      self._heads(T.as_tensor(self.attn_inter_k(m))),
+                                      self._heads(T.as_tensor(self.attn_inter_v(m))),
+                                      mem_attn_mask, _need_scores=False, _need_weights=False)
+        out = self.proj_inter(out, other=x)
+        if not self._pre_norm:
+            out = self.ln_inter(out)
+        return T.like_caller(T.as_tensor(self.ffn(out)), data)
+
+    def incremental_decode(self, *args, **kwargs):
+        raise NotImplementedError('incremental decoding is outside the built path '
+                                  '(SURVEY 8f rank 3 covers the full-sequence forward)')
+
+
+class TransformerDecoder(nn.Module):
+    """models/transformer.py:738-840 (forward only)."""
+
+    def __init__(self, num_layers=6, recurrent=False, units=512, mem_units=None, hidden_size=2048,
+                 num_heads=8, max_shift=None, activation_dropout=0.0, dropout=0.1,
+                 attention_dropout=0.1, layer_norm_eps=1E-5, data_norm=False, pre_norm=False,
+                 weight_initializer=None, bias_initializer='zeros', activation='relu',
+                 dtype='float32', layout='NT'):
+        super().__init__()
+        self._dtype = dtype
+        self._units = units
+        self._mem_units = mem_units
+        self.num_layers = num_layers
+        self.recurrent = recurrent
+        self.max_shift = max_shift
+        self._data_norm = data_norm
+        self._pre_norm = pre_norm
+        self._layout = layout
+        assert layout in ['TN', 'NT'], 'Invalid layout received = {}. ' \
+                                       'Only "TN" and "NT" are accepted!'.format(layout)
+        if self._data_norm:
+            self.ln_data = LayerNorm(epsilon=layer_norm_eps, in_channels=units, dtype=dtype)
+        if self._pre_norm:
+            self.ln_final = LayerNorm(epsilon=layer_norm_eps, in_channels=units, dtype=dtype)
+        real_num_layers = 1 if recurrent else num_layers
+        self.layers = nn.ModuleList([
+            TransformerDecoderLayer(units=units, mem_units=mem_units, hidden_size=hidden_size,
+                                    num_heads=num_heads, activation_dropout=activation_dropout,
+                                    dropout=dropout, attention_dropout=attention_dropout,
+                                    layer_norm_eps=layer_norm_eps,
+                                    weight_initializer=weight_initializer,
+                                    bias_initializer=bias_initializer, activation=activation,
+                                    pre_norm=pre_norm, layout=layout, dtype=dtype)
+            for _ in range(real_num_layers)])
+
+    @property
+    def units(self):
+        return self._units
+
+    @property
+    def layout(self) -> str:
+        return self._layout
+
+    def forward(self, data, valid_length, mem_data, mem_valid_length):
+        """models/transformer.py:789-840."""
+        out = data
+        if self._data_norm:
+            out = self.ln_data(out)
+        self_causal_mask = gen_self_attn_mask(data, valid_length, dtype=self._dtype,
+                                              attn_type='causal', layout=self._layout)
+        mem_attn_mask = gen_mem_attn_mask(mem_data, mem_valid_length, data, valid_length,
+                                          dtype=self._dtype, layout=self._layout)
+        for i in range(self.num_layers):
+            layer = self.layers[0] if self.recurrent else self.layers[i]
+            out = layer(out, mem_data, self_causal_mask, mem_attn_mask)
         if self._pre_norm:
             out = self.ln_final(out)
         return out

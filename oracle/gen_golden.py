@@ -164,6 +164,51 @@ def main():
     run_layers('enc_tiny_relu_vl1', 32, 64, 4, 3, 20, 1e-5, 2, [20, 1, 9], 23, act='relu')
     # head dim 64 (the MFMA fast path), ragged incl. vl=1 and vl=L
     run_layers('enc_d64', 128, 512, 2, 3, 128, 1e-12, 2, [128, 1, 77], 24)
+    # ---- TransformerDecoderLayer x 2 (torch/models/transformer.py:114-275), post-norm.  The masks
+    # are built here (causal self mask by the sibling; the memory mask by its definition
+    # attention_cell.py:186-274 -- the sibling's gen_mem_attn_mask reads a shape wrongly) ----
+    def run_decoder(cfgname, U, MU, F, H, B, L, LM, eps, vl, mvl, seed, act='relu'):
+        rng = np.random.default_rng(seed)
+        layers = [tr.TransformerDecoderLayer(units=U, mem_units=MU, hidden_size=F, num_heads=H,
+                                             activation_dropout=0.0, dropout=0.0,
+                                             attention_dropout=0.0, layer_norm_eps=eps,
+                                             activation=act, layout='NT').double().eval()
+                  for _ in range(2)]
+        out = {}
+        ren = {'ln_in.weight': 'ln_in.gamma', 'ln_in.bias': 'ln_in.beta',
+               'ln_inter.weight': 'ln_inter.gamma', 'ln_inter.bias': 'ln_inter.beta',
+               'ffn.layer_norm.weight': 'ffn.layer_norm.gamma',
+               'ffn.layer_norm.bias': 'ffn.layer_norm.beta'}
+        for li, layer in enumerate(layers):
+            with th.no_grad():
+                for n_, prm in layer.named_parameters():
+                    if prm.ndim == 2:
+                        w = np.clip(rng.standard_normal(tuple(prm.shape)) * 0.05, -0.1, 0.1)
+                    elif n_.endswith(('ln_in.weight', 'ln_inter.weight', 'layer_norm.weight')):
+                        w = 1.0 + 0.1 * rng.standard_normal(tuple(prm.shape))
+                    else:
+                        w = 0.1 * rng.standard_normal(tuple(prm.shape))
+                    prm.copy_(t(w.astype(np.float32)).double())
+            for kk, vv in layer.state_dict().items():
+                out['L{}/{}'.format(li, ren.get(kk, kk))] = vv.numpy().astype(np.float32)
+        x = rng.standard_normal((B, L, U)).astype(np.float32)
+        mem = rng.standard_normal((B, LM, MU)).astype(np.float32)
+        vl, mvl = np.asarray(vl, dtype=np.int64), np.asarray(mvl, dtype=np.int64)
+        out.update(x=x, mem=mem, valid_length=vl, mem_valid_length=mvl)
+        with th.no_grad():
+            causal = ac.gen_self_attn_mask(t(x), t(vl), attn_type='causal', layout='NT')
+            mm = ((th.arange(LM)[None, None, :] < t(mvl)[:, None, None]) &
+                  (th.arange(L)[None, :, None] < t(vl)[:, None, None]))
+            out['self_causal_mask'], out['mem_attn_mask'] = causal.numpy(), mm.numpy()
+            h = t(x).double()
+            for li, layer in enumerate(layers):
+                h = layer(h, t(mem).double(), causal, mm)
+                out['out_L{}'.format(li)] = h.numpy()
+        np.savez_compressed(os.path.join(OUT, cfgname + '.npz'), **out)
+
+    run_decoder('dec_tiny', 48, 40, 64, 2, 3, 7, 9, 1e-5, [7, 1, 4], [9, 3, 1], 31)
+    run_decoder('dec_d64', 128, 128, 256, 2, 3, 40, 72, 1e-5, [40, 1, 23], [72, 64, 5], 32,
+                act='gelu')
     print('wrote fixtures to', OUT)
 
 

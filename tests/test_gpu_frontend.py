@@ -214,3 +214,103 @@ def test_roberta_and_electra_models(nlp, dtype):
     want_ctx, _ = ref.electra_encoder(proj, vl, olayers, H, 1e-12, 'gelu')
     assert rel_err(to_np(ctx), want_ctx) < t
     assert torch.equal(pooled, ctx[:, 0, :])
+
+
+# ------------------------------------------------------------------ decoder
+import os  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _dec_params(g, li):
+    pre = 'L{}/'.format(li)
+    return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('name,H,act', [('dec_tiny', 2, 'relu'), ('dec_d64', 2, 'gelu')])
+def test_decoder_layer_goldens(nlp, dtype, name, H, act):
+    """TransformerDecoderLayer.forward (models/transformer.py:513-598) against the goldens of
+    the torch sibling (fp32) / the oracle on bf16-rounded inputs (bf16); dec_d64 runs the fused
+    attention kernel with causal and memory byte masks and Lq != Lm."""
+    from gluonnlp_amd.models import TransformerDecoderLayer
+    g = np.load(os.path.join(G, name + '.npz'))
+    x, mem = g['x'], g['mem']
+    U, MU = x.shape[-1], mem.shape[-1]
+    F = g['L0/ffn.ffn_1.weight'].shape[0]
+    dn = 'float32' if dtype == torch.float32 else 'bfloat16'
+    causal = torch.from_numpy(g['self_causal_mask']).cuda()
+    mm = torch.from_numpy(g['mem_attn_mask']).cuda()
+    h = to_dev(x, dtype)
+    md = to_dev(mem, dtype)
+    ho = prep(x, dtype)
+    t = tol(dtype) * (1 if dtype == torch.float32 else 2)
+    for li in range(2):
+        p = _dec_params(g, li)
+        layer = TransformerDecoderLayer(units=U, mem_units=MU, hidden_size=F, num_heads=H,
+                                        layer_norm_eps=1e-5, activation=act, dtype=dn)
+        load_params(layer, p, dtype)
+        h = layer(h, md, causal, mm)
+        if dtype == torch.float32:
+            want = g['out_L{}'.format(li)]
+        else:
+            ho = ref.transformer_decoder_layer(ho, prep(mem, dtype), g['self_causal_mask'],
+                                               g['mem_attn_mask'],
+                                               {k: prep(v, dtype) for k, v in p.items()}, H, 1e-5,
+                                               False, act)
+            want = ho
+        assert rel_err(to_np(h), want) < t, li
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout,pre_norm,recurrent', [('NT', False, False), ('TN', True, False),
+                                                       ('NT', True, True)])
+def test_transformer_decoder(nlp, dtype, layout, pre_norm, recurrent):
+    """TransformerDecoder.forward (models/transformer.py:789-840): masks from the valid lengths,
+    data_norm, pre_norm with the MX residual, recurrent weight sharing, both layouts."""
+    from gluonnlp_amd.models import TransformerDecoder
+    rng = np.random.default_rng(41)
+    U, MU, F, H, NL, B, L, LM = 64, 48, 128, 4, 2, 3, 18, 26
+    dn = 'float32' if dtype == torch.float32 else 'bfloat16'
+    m = TransformerDecoder(num_layers=NL, recurrent=recurrent, units=U, mem_units=MU,
+                           hidden_size=F, num_heads=H, data_norm=True, pre_norm=pre_norm,
+                           activation='gelu', dtype=dn, layout=layout)
+
+    def layer_params():
+        lin = lambda n, k: ref.trunc_norm(rng, (n, k), 0.05)
+        vec = lambda n, c=0.0: (c + 0.1 * rng.standard_normal(n)).astype(np.float32)
+        p = {}
+        for nm, n, k in [('attn_in_qkv', 3 * U, U), ('proj_in', U, U), ('attn_inter_q', U, U),
+                         ('attn_inter_k', U, MU), ('attn_inter_v', U, MU), ('proj_inter', U, U),
+                         ('ffn.ffn_1', F, U), ('ffn.ffn_2', U, F)]:
+            p[nm + '.weight'], p[nm + '.bias'] = lin(n, k), vec(n)
+        for nm in ['ln_in', 'ln_inter', 'ffn.layer_norm']:
+            p[nm + '.gamma'], p[nm + '.beta'] = vec(U, 1.0), vec(U)
+        return p
+    layers = [layer_params() for _ in range(1 if recurrent else NL)]
+    ln_data = {'gamma': (1 + 0.1 * rng.standard_normal(U)).astype(np.float32),
+               'beta': (0.1 * rng.standard_normal(U)).astype(np.float32)}
+    ln_final = {'gamma': (1 + 0.1 * rng.standard_normal(U)).astype(np.float32),
+                'beta': (0.1 * rng.standard_normal(U)).astype(np.float32)}
+    full = {'ln_data.gamma': ln_data['gamma'], 'ln_data.beta': ln_data['beta']}
+    if pre_norm:
+        full.update({'ln_final.gamma': ln_final['gamma'], 'ln_final.beta': ln_final['beta']})
+    for i, lp in enumerate(layers):
+        full.update({'layers.{}.{}'.format(i, k): v for k, v in lp.items()})
+    load_params(m, full, dtype)
+    shape = (B, L, U) if layout == 'NT' else (L, B, U)
+    mshape = (B, LM, MU) if layout == 'NT' else (LM, B, MU)
+    x, mem = rng.standard_normal(shape), rng.standard_normal(mshape)
+    vl, mvl = np.array([L, 1, 11]), np.array([LM, 9, 1])
+    got = m(to_dev(x, dtype), torch.from_numpy(vl).cuda(), to_dev(mem, dtype),
+            torch.from_numpy(mvl).cuda())
+    o = lambda a: prep(a, dtype)
+    want = ref.transformer_decoder(
+        o(x), vl, o(mem), mvl, [{k: o(v) for k, v in lp.items()} for lp in layers], H, 1e-5,
+        pre_norm, 'gelu', layout, recurrent=recurrent, num_layers=NL,
+        ln_data={k: o(v) for k, v in ln_data.items()},
+        ln_final={k: o(v) for k, v in ln_final.items()})
+    t = tol(dtype) * (1 if dtype == torch.float32 else 3)   # NL layers x 3 sub-blocks of bf16
+    assert rel_err(to_np(got), want) < t
+    with pytest.raises(NotImplementedError):
+        m.layers[0].incremental_decode(None, None, None, None)

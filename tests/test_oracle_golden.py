@@ -328,3 +328,40 @@ def test_embedding_front_end_against_torch_ops(layout):
     assert np.abs(ref.apply_pooling(seq, w, bb, 'tanh', layout) -
                   torch.tanh(F.linear(t(cls), t(w), t(bb))).numpy()).max() < 1e-12
     assert np.array_equal(ref.apply_pooling(seq, None, None, 'tanh', layout), cls)
+
+
+@pytest.mark.parametrize('name,H,act', [('dec_tiny', 2, 'relu'), ('dec_d64', 2, 'gelu')])
+def test_decoder_layer_goldens(name, H, act):
+    """the restated TransformerDecoderLayer (models/transformer.py:513-598)
+    against the torch sibling's decoder layer (post-norm, where the two texts agree), two layers,
+    ragged target and memory lengths incl. 1; and the decoder's masks against the stored ones."""
+    g = np.load(os.path.join(G, name + '.npz'))
+    x, mem, vl, mvl = g['x'], g['mem'], g['valid_length'], g['mem_valid_length']
+    causal = ref.gen_self_attn_mask(x, vl, attn_type='causal')
+    mm = ref.gen_mem_attn_mask(mem, mvl, x, vl)
+    assert np.array_equal(causal, g['self_causal_mask'])
+    assert np.array_equal(mm, g['mem_attn_mask'])
+    h = x.astype(np.float64)
+    layers = []
+    for li in range(2):
+        p = {k[len('L{}/'.format(li)):]: g[k].astype(np.float64) for k in g.files
+             if k.startswith('L{}/'.format(li))}
+        layers.append(p)
+        h = ref.transformer_decoder_layer(h, mem.astype(np.float64), causal, mm, p, H, 1e-5, False,
+                                          act)
+        assert np.abs(h - g['out_L{}'.format(li)]).max() < 1e-9
+    full = ref.transformer_decoder(x.astype(np.float64), vl, mem.astype(np.float64), mvl, layers,
+                                   H, 1e-5, False, act)
+    assert np.abs(full - g['out_L1']).max() < 1e-9
+    # TN layout gives the transposed result
+    tn = ref.transformer_decoder(np.swapaxes(x, 0, 1).astype(np.float64), vl,
+                                 np.swapaxes(mem, 0, 1).astype(np.float64), mvl, layers, H, 1e-5,
+                                 False, act, layout='TN')
+    assert np.abs(np.swapaxes(tn, 0, 1) - full).max() < 1e-9
+    # pre_norm: the MX text adds the NORMALISED input (transformer.py:569-570,582-583); the
+    # sibling adds the raw one -- the two must differ, and the restatement follows the MX text
+    a = ref.transformer_decoder_layer(h, mem.astype(np.float64), causal, mm, layers[0], H, 1e-5,
+                                      True, act, residual_normed=True)
+    b = ref.transformer_decoder_layer(h, mem.astype(np.float64), causal, mm, layers[0], H, 1e-5,
+                                      True, act, residual_normed=False)
+    assert np.abs(a - b).max() > 1e-3
