@@ -193,12 +193,11 @@ static void launch_act(const DenseArgs &a0, hipStream_t s) {
   a.group_m = gm ? atoi(gm) : 8;
   if (a.group_m < 1) a.group_m = 1;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr;
+  attr.once([&] {
     (void)hipFuncSetAttribute((const void *)dense_bf16_kernel<BM, BN, WM, WN, ACT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  });
   dense_bf16_kernel<BM, BN, WM, WN, ACT>
       <<<dim3((unsigned)(a.tiles_m * a.tiles_n)), WM * WN * 64, LDS, s>>>(a);
 }

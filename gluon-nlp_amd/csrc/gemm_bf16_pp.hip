@@ -32,7 +32,7 @@ struct DensePPArgs {
   bf16 *out;
   int64_t M, N, K, ldx, ldo, ldother;
   int combine;
-  int tiles_m, tiles_n, group_m, dbg;
+  int tiles_m, tiles_n, group_m;
 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -274,11 +274,7 @@ dense_bf16_pp_kernel(DensePPArgs a) {
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-      if (a.dbg & 1) {   // timing-only build switch: keep the values alive, skip the store
-        asm volatile("" ::"v"(o));
-      } else if (ok) {
-        *reinterpret_cast<bf16x8 *>(a.out + m * a.ldo + n) = o;
-      }
+      if (ok) *reinterpret_cast<bf16x8 *>(a.out + m * a.ldo + n) = o;
     }
     GNLP_LGKM0();   // the wave's reads are done before the image is overwritten
     __builtin_amdgcn_sched_barrier(0);
@@ -297,12 +293,11 @@ bool mfma_bf16_dense_pp_supported(int64_t N, int64_t ldo, int64_t ldother, const
 template <int ACT>
 static void launch_pp_act(const DensePPArgs &a, hipStream_t s) {
   constexpr int LDS = 5 * 2 * 128 * 128;   // 3 A + 2 B K-tile buffers = 160 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr;
+  attr.once([&] {
     (void)hipFuncSetAttribute((const void *)dense_bf16_pp_kernel<ACT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  });
   dense_bf16_pp_kernel<ACT><<<dim3((unsigned)(a.tiles_m * a.tiles_n)), 512, LDS, s>>>(a);
 }
 
@@ -320,8 +315,6 @@ void launch_mfma_bf16_dense_pp(void *out, const void *x, const void *w, const vo
   const char *gm = getenv("GNLP_GROUP_M");   // developer knob
   a.group_m = gm ? atoi(gm) : 8;
   if (a.group_m < 1) a.group_m = 1;
-  const char *dbg = getenv("GNLP_GEMM_DBG");  // developer knob (timing ablations), default 0
-  a.dbg = dbg ? atoi(dbg) : 0;
   switch (act) {
     case GNLP_ACT_RELU: launch_pp_act<GNLP_ACT_RELU>(a, s); break;
     case GNLP_ACT_GELU_ERF: launch_pp_act<GNLP_ACT_GELU_ERF>(a, s); break;

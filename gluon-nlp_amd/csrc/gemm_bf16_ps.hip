@@ -450,14 +450,16 @@ bool mfma_bf16_dense_ps_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, 
   return true;
 }
 
-static int cu_count() {
-  static int n = 0;
+static int cu_count() {   // of the current device
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = cache[dev & 63].load(std::memory_order_relaxed);
   if (n == 0) {
-    int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-      n = p.multiProcessorCount;
+    n = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 0;
     if (n < 8) n = 256;
+    cache[dev & 63].store(n, std::memory_order_relaxed);
   }
   return n;
 }
@@ -465,12 +467,11 @@ static int cu_count() {
 template <int ACT, bool HAS_OTHER>
 static void launch_ps_act(const DensePSArgs &a, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * 128 + 4 * 4096 + 16384;   // 160 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr;
+  attr.once([&] {
     (void)hipFuncSetAttribute((const void *)dense_bf16_ps_kernel<ACT, HAS_OTHER>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  });
   const int nt = a.tiles_m * a.tiles_n;
   int grid = cu_count() & ~7;            // one workgroup per CU, a multiple of the 8 XCDs
   const int need = ((nt + 7) / 8) * 8;   // fewer tiles than CUs: one tile each

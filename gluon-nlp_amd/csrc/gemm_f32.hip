@@ -167,12 +167,11 @@ bool mfma_f32_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int6
 template <int ACT>
 static void launch_f32_act(const DenseArgsF32 &a, hipStream_t s) {
   constexpr int LDS = 2 * 256 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr;
+  attr.once([&] {
     (void)hipFuncSetAttribute((const void *)dense_f32_kernel<ACT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  });
   dense_f32_kernel<ACT><<<dim3((unsigned)(a.tiles_m * a.tiles_n)), 256, LDS, s>>>(a);
 }
 

@@ -4,7 +4,26 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace gnlp {
+
+// Function attributes (hipFuncSetAttribute) are per device: run `f` once per device that launches
+// the kernel.  Racing threads may both run it, which is harmless; none launches before it ran.
+struct PerDeviceFlag {
+  std::atomic<uint64_t> mask{0};
+  template <class F>
+  void once(F f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(mask.load(std::memory_order_acquire) & bit)) {
+      f();
+      mask.fetch_or(bit, std::memory_order_release);
+    }
+  }
+};
+
 
 // relative_position_bucket thresholds (see elementwise.hip); passed by value as a kernel argument
 struct BucketTable {
