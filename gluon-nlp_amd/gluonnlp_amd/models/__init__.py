@@ -5,4 +5,4 @@ from .transformer import (TransformerEncoderLayer, TransformerEncoder,  # noqa: 
 from .bert import BertTransformer, BertModel  # noqa: F401
 from .roberta import RobertaEncoder, RobertaModel  # noqa: F401
 from .electra import ElectraEncoder, ElectraModel  # noqa: F401
-from .t5 import T5Block, T5Encoder  # noqa: F401
+from .t5 import T5Block, T5Encoder, T5Decoder, T5Model  # noqa: F401

@@ -1,6 +1,8 @@
-"""T5Block (encoder form) / T5Encoder -- mirrors the encoder half of ``gluonnlp/models/t5.py``
-(reference src/gluonnlp/models/t5.py:173-350, 492-572, 576-711).  The decoder / incremental
-decoding is outside the encoder hot path."""
+"""T5Block / T5Encoder / T5Decoder / T5Model -- mirrors ``gluonnlp/models/t5.py`` (reference
+src/gluonnlp/models/t5.py:173-350, 374-572, 576-711, 715-964, 968-1189).  The encoder stack is one
+C call; the decoder runs block by block on the same kernels: causal and memory
+masks are byte masks to the fused attention kernel, Lq != Lm for the memory, Lq = 1 when decoding
+incrementally."""
 import ctypes
 
 import torch
@@ -8,11 +10,11 @@ from torch import nn
 
 from .. import _lib
 from .. import _tensor as T
-from ..attention_cell import (MultiHeadAttentionCell, RelAttentionScoreCell, gen_rel_position,
-                              gen_self_attn_mask, mask_predicate)
-from ..layers import Dense, PositionwiseFFN, RMSNorm, ffn_params_struct
+from ..attention_cell import (MultiHeadAttentionCell, RelAttentionScoreCell, gen_mem_attn_mask,
+                              gen_rel_position, gen_self_attn_mask, mask_predicate)
+from ..layers import Dense, Embedding, PositionwiseFFN, RMSNorm, ffn_params_struct
 
-__all__ = ['T5Block', 'T5Encoder']
+__all__ = ['T5Block', 'T5Encoder', 'T5Decoder', 'T5Model']
 
 
 def _normal(std):
@@ -29,9 +31,6 @@ class T5Block(nn.Module):
                  layer_norm_eps=1E-6, activation='relu', init_factor=1.0, layout='NT',
                  dtype='float32'):
         super().__init__()
-        if is_decoder:
-            raise NotImplementedError('T5 decoder blocks are outside the encoder hot path '
-                                      '(SURVEY.md §8f)')
         self._d_model, self._d_kv, self._d_ff = d_model, d_kv, d_ff
         self._is_decoder = is_decoder
         self._num_heads = num_heads
@@ -56,6 +55,21 @@ class T5Block(nn.Module):
             layout='NTK' if layout == 'NT' else 'TNK', use_einsum=False)
         self.self_attn_proj = Dense(d_model, self._inner_dim, use_bias=False, dtype=dtype,
                                     weight_initializer=_normal(self._inner_dim ** -0.5 * init_factor))
+        if self._is_decoder:
+            self.cross_attn_layer_norm = RMSNorm(in_channels=d_model, center=False, scale=True,
+                                                 variance_epsilon=layer_norm_eps, dtype=dtype)
+            self.cross_attn_q = Dense(self._inner_dim, d_model, use_bias=False, dtype=dtype,
+                                      weight_initializer=_normal((d_model * d_kv) ** -0.5 * init_factor))
+            self.cross_attn_k = Dense(self._inner_dim, d_model, use_bias=False, dtype=dtype,
+                                      weight_initializer=_normal(d_model ** -0.5 * init_factor))
+            self.cross_attn_v = Dense(self._inner_dim, d_model, use_bias=False, dtype=dtype,
+                                      weight_initializer=_normal(d_model ** -0.5 * init_factor))
+            self.cross_attn = MultiHeadAttentionCell(
+                query_units=self._inner_dim, num_heads=num_heads, attention_dropout=dropout_prob,
+                scaled=False, normalized=False, dtype=dtype,
+                layout='NTK' if layout == 'NT' else 'TNK', use_einsum=False)
+            self.cross_attn_proj = Dense(d_model, self._inner_dim, use_bias=False, dtype=dtype,
+                                         weight_initializer=_normal(self._inner_dim ** -0.5 * init_factor))
         assert activation in ['relu', 'gated-gelu'], \
             '{} is not supported. Please choose from "relu" and "gated-gelu"'.format(activation)
         self._activation = activation
@@ -91,24 +105,74 @@ class T5Block(nn.Module):
         c.ln_eps = self._layer_norm_eps
         return c
 
+    @property
+    def state_batch_axis(self):
+        assert self._is_decoder, 'state_batch_axis() is available for decoder only.'
+        return (0, 0) if self.layout == 'NT' else (1, 1)
+
+    def _init_key_value(self, batch_size, ctx, dtype='float32'):
+        """models/t5.py:374-381: empty (B, 0, H, d_kv) / (0, B, H, d_kv) key and value."""
+        assert self._is_decoder, '_init_key_value() is available for decoder only.'
+        shape = ((batch_size, 0, self._num_heads, self._d_kv) if self.layout == 'NT'
+                 else (0, batch_size, self._num_heads, self._d_kv))
+        dt = T.torch_dtype(dtype)
+        return (torch.zeros(shape, dtype=dt, device=ctx), torch.zeros(shape, dtype=dt, device=ctx))
+
+    def transpose_for_scores(self, x):
+        """(B, L, inner) -> (B, L, H, d_kv) or (L, B, inner) -> (L, B, H, d_kv).  t5.py:383-389."""
+        x = T.as_tensor(x)
+        return x.reshape(x.shape[0], x.shape[1], self._num_heads, -1)
+
+    def _cross_and_ffn(self, hidden_states, mem_states, mem_attn_mask):
+        out = self.cross_attn_layer_norm(hidden_states)
+        q = self.transpose_for_scores(self.cross_attn_q(out))
+        k = self.transpose_for_scores(self.cross_attn_k(mem_states))
+        v = self.transpose_for_scores(self.cross_attn_v(mem_states))
+        out, _ = self.cross_attn(q, k, v, mem_attn_mask, _need_scores=False, _need_weights=False)
+        hidden_states = self.cross_attn_proj(out, other=hidden_states, combine='add')
+        return self.ffn(hidden_states)
+
+    def incremental_decode(self, step_hidden_states, step_position_embeddings, past_key_value,
+                           mem_states, step_mem_attn_mask):
+        """One target position.  step_hidden_states (B, 1, d_model) / (1, B, d_model);
+        step_position_embeddings (H, 1, L_past + 1); past_key_value two (B, L_past, H, d_kv) /
+        (L_past, B, H, d_kv); step_mem_attn_mask (B, 1, L_src) -> (step_hidden_states,
+        (key, value)) with the step appended.  models/t5.py:391-490."""
+        assert self._is_decoder, 'incremental_decode() is available for decoder only.'
+        x = T.as_tensor(step_hidden_states)
+        out = self.self_attn_layer_norm(x)
+        q = self.transpose_for_scores(self.self_attn_q(out))
+        k = self.transpose_for_scores(self.self_attn_k(out))
+        v = self.transpose_for_scores(self.self_attn_v(out))
+        self_key = torch.cat([T.as_tensor(past_key_value[0]), k], dim=self._time_axis)
+        self_value = torch.cat([T.as_tensor(past_key_value[1]), v], dim=self._time_axis)
+        out, _ = self.self_attn(q, self_key, self_value, None, step_position_embeddings,
+                                _need_scores=False, _need_weights=False)
+        x = self.self_attn_proj(out, other=x, combine='add')
+        x = self._cross_and_ffn(x, mem_states, step_mem_attn_mask)
+        return T.like_caller(T.as_tensor(x), step_hidden_states), (self_key, self_value)
+
     def forward(self, hidden_states, self_attn_mask, position_embeddings, mem_states=None,
                 mem_attn_mask=None):
-        """models/t5.py:492-572 (encoder form)."""
+        """models/t5.py:492-572."""
         m = T.as_tensor(self_attn_mask)
-        pred = mask_predicate(m) if m is not None else ('ones', None)
-        if pred is not None:
-            vl = pred[1] if pred[0] == 'full' else None
-            return run_t5_blocks([self], hidden_states, vl, position_embeddings, None,
-                                 self._layout)
-        # arbitrary dense mask: op-by-op path through the same kernels (t5.py:537-571)
+        if not self._is_decoder:
+            pred = mask_predicate(m) if m is not None else ('ones', None)
+            if pred is not None:
+                vl = pred[1] if pred[0] == 'full' else None
+                return run_t5_blocks([self], hidden_states, vl, position_embeddings, None,
+                                     self._layout)
+        # arbitrary dense mask / decoder: op by op through the same kernels (t5.py:537-571)
         out = self.self_attn_layer_norm(hidden_states)
-        shp = tuple(out.shape[:2]) + (self._num_heads, self._d_kv)
-        q = self.self_attn_q(out).reshape(shp)
-        k = self.self_attn_k(out).reshape(shp)
-        v = self.self_attn_v(out).reshape(shp)
+        q = self.transpose_for_scores(self.self_attn_q(out))
+        k = self.transpose_for_scores(self.self_attn_k(out))
+        v = self.transpose_for_scores(self.self_attn_v(out))
         out, _ = self.self_attn(q, k, v, m, position_embeddings, _need_scores=False,
                                 _need_weights=False)
         hidden_states = self.self_attn_proj(out, other=hidden_states, combine='add')
+        if self._is_decoder:
+            return T.like_caller(T.as_tensor(self._cross_and_ffn(hidden_states, mem_states,
+                                                                 mem_attn_mask)), hidden_states)
         return self.ffn(hidden_states)
 
 
@@ -186,3 +250,135 @@ class T5Encoder(nn.Module):
         position_embeddings = self.relative_position_encoder.self_attn_bias(L)
         return run_t5_blocks(list(self.layers), hidden_states, valid_length, position_embeddings,
                              self.final_layer_norm, self._layout)
+
+
+class T5Decoder(nn.Module):
+    """models/t5.py:715-964: unidirectional relative-position buckets, causal self-attention,
+    attention over the encoder memory."""
+
+    def __init__(self, d_model, d_kv, d_ff, num_layers=12, num_heads=12, dropout_prob=0.1,
+                 layer_norm_eps=1E-6, activation='relu', init_factor=1.0, layout='NT',
+                 dtype='float32'):
+        super().__init__()
+        self._d_model, self._d_kv, self._d_ff = d_model, d_kv, d_ff
+        self._num_layers = num_layers
+        self._num_heads = num_heads
+        self._inner_dim = num_heads * d_kv
+        self._dtype = dtype
+        assert layout in ['TN', 'NT'], \
+            'Invalid layout: {}. Only "TN" and "NT" are supported.'.format(layout)
+        self._layout = layout
+        self._time_axis = 1 if self.layout == 'NT' else 0
+        self.relative_position_encoder = RelAttentionScoreCell(
+            query_units=self._inner_dim, num_heads=num_heads, method='t5', bidirectional=False,
+            embed_initializer=_normal(d_model ** -0.5 * init_factor),
+            layout='NTK' if layout == 'NT' else 'TNK', dtype=dtype)
+        self.layers = nn.ModuleList([
+            T5Block(d_model=d_model, d_kv=d_kv, d_ff=d_ff, is_decoder=True, num_heads=num_heads,
+                    dropout_prob=dropout_prob, layer_norm_eps=layer_norm_eps,
+                    activation=activation, init_factor=init_factor, layout=layout, dtype=dtype)
+            for _ in range(num_layers)])
+        self.final_layer_norm = RMSNorm(in_channels=d_model, center=False, scale=True,
+                                        variance_epsilon=layer_norm_eps, dtype=dtype)
+
+    @property
+    def layout(self):
+        return self._layout
+
+    @property
+    def state_batch_axis(self):
+        return list(layer.state_batch_axis for layer in self.layers)
+
+    def _init_key_values(self, batch_size, ctx, dtype='float32'):
+        return list(layer._init_key_value(batch_size, ctx, dtype) for layer in self.layers)
+
+    def incremental_decode(self, step_hidden_states, position, past_key_values, mem_states,
+                           mem_valid_length):
+        """models/t5.py:812-893.  ``position`` (B,) is accepted as in the reference, which derives
+        the step's relative positions from the length of the cached keys instead (:863-870)."""
+        past = T.as_tensor(past_key_values[0][0])
+        L = past.shape[self._time_axis] + 1
+        # last row of the (L, L) bias = relative positions (mem_j - (L - 1)) of the new query
+        step_position_embeddings = self.relative_position_encoder.self_attn_bias(L)[
+            :, -1:, :].contiguous()
+        step_mem_attn_mask = gen_mem_attn_mask(mem_states, mem_valid_length, step_hidden_states,
+                                               dtype=self._dtype, layout=self.layout)
+        present_key_values = []
+        for i, layer in enumerate(self.layers):
+            step_hidden_states, present = layer.incremental_decode(
+                step_hidden_states, step_position_embeddings, past_key_values[i], mem_states,
+                step_mem_attn_mask)
+            present_key_values.append(present)
+        return self.final_layer_norm(step_hidden_states), present_key_values
+
+    def forward(self, hidden_states, valid_length, mem_states, mem_valid_length):
+        """models/t5.py:895-964."""
+        x = T.as_tensor(hidden_states)
+        L = x.shape[self._time_axis]
+        position_embeddings = self.relative_position_encoder.self_attn_bias(L)
+        self_attn_mask = gen_self_attn_mask(hidden_states, valid_length, dtype=self._dtype,
+                                            attn_type='causal', layout=self.layout)
+        mem_attn_mask = gen_mem_attn_mask(mem_states, mem_valid_length, hidden_states,
+                                          valid_length, dtype=self._dtype, layout=self.layout)
+        for layer in self.layers:
+            hidden_states = layer(hidden_states, self_attn_mask, position_embeddings, mem_states,
+                                  mem_attn_mask)
+        return self.final_layer_norm(hidden_states)
+
+
+class T5Model(nn.Module):
+    """T5 encoder-decoder (models/t5.py:968-1189): one input embedding shared by both stacks."""
+
+    def __init__(self, vocab_size=32128, d_model=768, d_kv=64, d_ff=3072, num_layers=12,
+                 num_heads=12, dropout_prob=0.1, layer_norm_eps=1E-6, activation='relu',
+                 init_factor=1.0, layout='NT', dtype='float32'):
+        super().__init__()
+        assert vocab_size > 0, 'Vocab size {} is not valid.'.format(vocab_size)
+        self._vocab_size = vocab_size
+        self._d_model, self._d_kv, self._d_ff = d_model, d_kv, d_ff
+        self._num_layers = num_layers
+        self._num_heads = num_heads
+        self._inner_dim = num_heads * d_kv
+        self._activation = activation
+        self._init_factor = init_factor
+        self._dtype = dtype
+        assert layout in ['TN', 'NT'], \
+            'Invalid layout: {}. Only "TN" and "NT" are supported.'.format(layout)
+        self._layout = layout
+        self._time_axis = 1 if self.layout == 'NT' else 0
+        self.input_embedding_layer = Embedding(input_dim=vocab_size, output_dim=d_model,
+                                               weight_initializer=_normal(1.0 * init_factor),
+                                               dtype=dtype)
+        kw = dict(d_model=d_model, d_kv=d_kv, d_ff=d_ff, num_layers=num_layers,
+                  num_heads=num_heads, dropout_prob=dropout_prob, layer_norm_eps=layer_norm_eps,
+                  activation=activation, init_factor=init_factor, layout=layout, dtype=dtype)
+        self.encoder = T5Encoder(**kw)
+        self.decoder = T5Decoder(**kw)
+
+    @property
+    def activation(self):
+        return self._activation
+
+    @property
+    def layout(self):
+        return self._layout
+
+    @property
+    def num_layers(self):
+        return self._num_layers
+
+    @property
+    def vocab_size(self):
+        return self._vocab_size
+
+    def encode(self, src_data, src_valid_length):
+        """token ids (B, L_src) / (L_src, B) -> (B, L_src, d_model) / (L_src, B, d_model)."""
+        return self.encoder(self.input_embedding_layer(src_data), src_valid_length)
+
+    def decode(self, tgt_data, tgt_valid_length, mem_states, mem_valid_length):
+        return self.decoder(self.input_embedding_layer(tgt_data), tgt_valid_length, mem_states,
+                            mem_valid_length)
+
+    def forward(self, src_data, src_valid_length, tgt_data, tgt_valid_length):
+        enc_out = self.encode(src_data, src_valid_length)
+        return self.decode(tgt_data, tgt_valid_length, enc_out, src_valid_length)

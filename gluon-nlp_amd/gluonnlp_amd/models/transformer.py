@@ -294,13 +294,59 @@ class TransformerDecoderLayer(nn.Module):
             out = self.ln_inter(out)
         return T.like_caller(T.as_tensor(self.ffn(out)), data)
 
-    def incremental_decode(self, *args, **kwargs):
-        raise NotImplementedError('incremental decoding is outside the built path '
-                                  '(SURVEY 8f rank 3 covers the full-sequence forward)')
+    @property
+    def state_batch_axis(self):
+        return (0, 0) if self.layout == 'NT' else (1, 1)
+
+    def init_states(self, batch_size, ctx, dtype='float32'):
+        """Empty key / value caches (B, 0, H, C) / (0, B, H, C).  models/transformer.py:607-635."""
+        d = self._units // self._num_heads
+        shape = ((batch_size, 0, self._num_heads, d) if self.layout == 'NT'
+                 else (0, batch_size, self._num_heads, d))
+        dt = T.torch_dtype(dtype)
+        return (torch.zeros(shape, dtype=dt, device=ctx), torch.zeros(shape, dtype=dt, device=ctx))
+
+    def incremental_decode(self, data, states, mem, mem_valid_length, mem_attn_mask=None):
+        """One target position: data (B, C_in); states = (keys, values) of the previous positions
+        -> (out (B, C_out), (keys, values) with this position appended).
+        models/transformer.py:637-734.  The self-attention needs no mask: every cached position
+        precedes the new one."""
+        x = T.as_tensor(data)
+        if self._pre_norm:
+            x = self.ln_in(x)
+        time_axis = 1 if self.layout == 'NT' else 0
+        x = T.as_tensor(x).unsqueeze(time_axis)
+        prev_key, prev_value = states
+        if mem_attn_mask is None:
+            mem_attn_mask = gen_mem_attn_mask(mem, mem_valid_length, x, None, dtype=self._dtype,
+                                              layout=self.layout)
+        qkv = T.as_tensor(self.attn_in_qkv(x))
+        U = self._units
+        q, k, v = qkv[..., :U], qkv[..., U:2 * U], qkv[..., 2 * U:]
+        new_key = torch.cat([T.as_tensor(prev_key), self._heads(k)], dim=time_axis)
+        new_value = torch.cat([T.as_tensor(prev_value), self._heads(v)], dim=time_axis)
+        out, _ = self.self_attention(self._heads(q), new_key, new_value, None,
+                                     _need_scores=False, _need_weights=False)
+        out = self.proj_in(out, other=x)
+        if not self._pre_norm:
+            out = self.ln_in(out)
+        x = T.as_tensor(out)
+        if self._pre_norm:
+            x = self.ln_inter(x)
+        m = T.as_tensor(mem)
+        out, _ = self.inter_attention(self._heads(T.as_tensor(self.attn_inter_q(x))),
+                                      self._heads(T.as_tensor(self.attn_inter_k(m))),
+                                      self._heads(T.as_tensor(self.attn_inter_v(m))),
+                                      mem_attn_mask, _need_scores=False, _need_weights=False)
+        out = self.proj_inter(out, other=x)
+        if not self._pre_norm:
+            out = self.ln_inter(out)
+        out = T.as_tensor(self.ffn(out))
+        return T.like_caller(out.reshape(-1, out.shape[-1]), data), (new_key, new_value)
 
 
 class TransformerDecoder(nn.Module):
-    """models/transformer.py:738-840 (forward only)."""
+    """models/transformer.py:738-959."""
 
     def __init__(self, num_layers=6, recurrent=False, units=512, mem_units=None, hidden_size=2048,
                  num_heads=8, max_shift=None, activation_dropout=0.0, dropout=0.1,
@@ -357,3 +403,33 @@ class TransformerDecoder(nn.Module):
         if self._pre_norm:
             out = self.ln_final(out)
         return out
+
+    @property
+    def state_batch_axis(self):
+        return [(self.layers[0] if self.recurrent else self.layers[i]).state_batch_axis
+                for i in range(self.num_layers)]
+
+    def init_states(self, batch_size, ctx, dtype='float32'):
+        """models/transformer.py:852-882."""
+        return [(self.layers[0] if self.recurrent else self.layers[i]).init_states(
+            batch_size=batch_size, ctx=ctx, dtype=dtype) for i in range(self.num_layers)]
+
+    def incremental_decode(self, data, states, mem, mem_valid_length):
+        """data (B, C_in), one cache pair per layer -> (out (B, C_out), new caches).
+        models/transformer.py:884-959: the memory mask (B, 1, mem_length) is built once."""
+        out = data
+        if self._data_norm:
+            out = self.ln_data(out)
+        time_axis = 0 if self.layout == 'TN' else 1
+        step = T.as_tensor(data).unsqueeze(time_axis)
+        mem_attn_mask = gen_mem_attn_mask(mem, mem_valid_length, step, None, dtype=self._dtype,
+                                          layout=self._layout)
+        new_states = []
+        for i in range(self.num_layers):
+            layer = self.layers[0] if self.recurrent else self.layers[i]
+            out, new_state = layer.incremental_decode(out, states[i], mem, mem_valid_length,
+                                                      mem_attn_mask)
+            new_states.append(new_state)
+        if self._pre_norm:
+            out = self.ln_final(out)
+        return out, new_states

@@ -312,5 +312,22 @@ def test_transformer_decoder(nlp, dtype, layout, pre_norm, recurrent):
         ln_final={k: o(v) for k, v in ln_final.items()})
     t = tol(dtype) * (1 if dtype == torch.float32 else 3)   # NL layers x 3 sub-blocks of bf16
     assert rel_err(to_np(got), want) < t
-    with pytest.raises(NotImplementedError):
-        m.layers[0].incremental_decode(None, None, None, None)
+    # incremental decoding (models/transformer.py:884-959): feeding the target one position at a
+    # time, with the key / value caches, reproduces the full forward on every valid position
+    xd, memd = to_dev(x, dtype), to_dev(mem, dtype)
+    mvld = torch.from_numpy(mvl).cuda()
+    states = m.init_states(B, 'cuda', dn)
+    assert m.state_batch_axis == [(0, 0) if layout == 'NT' else (1, 1)] * NL
+    tax = 1 if layout == 'NT' else 0
+    steps = []
+    for i in range(L):
+        step_in = xd[:, i] if layout == 'NT' else xd[i]
+        out_i, states = m.incremental_decode(step_in, states, memd, mvld)
+        assert tuple(out_i.shape) == (B, U)
+        assert states[0][0].shape[tax] == i + 1
+        steps.append(to_np(out_i))
+    inc = np.stack(steps, axis=tax)
+    full = to_np(got)
+    for b in range(B):
+        sl = (b, slice(0, vl[b])) if layout == 'NT' else (slice(0, vl[b]), b)
+        assert rel_err(inc[sl], full[sl]) < (1e-5 if dtype == torch.float32 else 2e-2), b

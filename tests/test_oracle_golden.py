@@ -365,3 +365,23 @@ def test_decoder_layer_goldens(name, H, act):
     b = ref.transformer_decoder_layer(h, mem.astype(np.float64), causal, mm, layers[0], H, 1e-5,
                                       True, act, residual_normed=False)
     assert np.abs(a - b).max() > 1e-3
+
+
+@pytest.mark.parametrize('name', ['t5_hf_relu', 't5_hf_gated'])
+def test_t5_encoder_decoder_against_hf_goldens(name):
+    """The whole T5 path of the oracle (bidirectional / unidirectional buckets, un-scaled
+    attention + bias, causal + memory masks, RMSNorm pre-norm blocks, relu and gated-gelu FFN)
+    against HuggingFace's T5Model in float64, with the weights renamed the way the reference's
+    converter renames them -- the reference's own equivalence check
+    (scripts/conversion_toolkits/convert_t5.py:203-232, 1e-3 there, 5e-6 here: HF's T5LayerNorm
+    takes its mean of squares in float32 whatever the model dtype), on the valid target positions as
+    that check does (HF leaves padded query rows unmasked)."""
+    g = load(name + '.npz')
+    p = {k[2:]: g[k] for k in g.files if k.startswith('p:')}
+    svl, tvl = g['src_valid_length'], g['tgt_valid_length']
+    enc, dec = ref.t5_model(g['src'], svl, g['tgt'], tvl, p, int(g['num_layers']),
+                            int(g['num_heads']),
+                            activation_name='gated-gelu' if int(g['gated']) else 'relu')
+    for b in range(len(svl)):
+        assert_allclose(enc[b, :svl[b]], g['enc_out'][b, :svl[b]], rtol=0, atol=5e-6)
+        assert_allclose(dec[b, :tvl[b]], g['dec_out'][b, :tvl[b]], rtol=0, atol=5e-6)
