@@ -331,3 +331,43 @@ def test_transformer_decoder(nlp, dtype, layout, pre_norm, recurrent):
     for b in range(B):
         sl = (b, slice(0, vl[b])) if layout == 'NT' else (slice(0, vl[b]), b)
         assert rel_err(inc[sl], full[sl]) < (1e-5 if dtype == torch.float32 else 2e-2), b
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['NT', 'TN'])
+@pytest.mark.parametrize('name', ['bert_hf_d64', 'bert_hf_h4'])
+def test_bert_model_against_hf_goldens(nlp, name, layout, dtype):
+    """BertModel (ids -> contextual embeddings, pooled) against HuggingFace's BertModel outputs
+    (tests/golden/bert_hf_*.npz, oracle/gen_golden_bert_hf.py) in fp32; in bf16 against the oracle
+    -- pinned to the same goldens at 1e-10 -- on bf16-rounded parameters."""
+    from gluonnlp_amd.models import BertModel
+    from tests.test_oracle_golden import bert_from_ids
+    g = np.load(os.path.join(G, name + '.npz'))
+    p = {k[2:]: g[k] for k in g.files if k.startswith('p:')}
+    V, U = p['word_embed.weight'].shape
+    NL, H = int(g['num_layers']), int(g['num_heads'])
+    F = p['encoder.all_layers.0.ffn.ffn_1.weight'].shape[0]
+    dn = 'float32' if dtype == torch.float32 else 'bfloat16'
+    m = BertModel(vocab_size=V, units=U, hidden_size=F, num_layers=NL, num_heads=H,
+                  max_length=p['token_pos_embed._embed.weight'].shape[0], dtype=dn, layout=layout)
+    load_params(m, p, dtype)
+    vl = g['valid_length']
+    ids, tt = g['ids'], g['token_types']
+    if layout == 'TN':
+        ids, tt = ids.T, tt.T
+    seq, pooled = m(torch.from_numpy(np.ascontiguousarray(ids)).cuda(),
+                    torch.from_numpy(np.ascontiguousarray(tt)).cuda(),
+                    torch.from_numpy(vl).cuda())
+    seq_n = to_np(seq)
+    if layout == 'TN':
+        seq_n = seq_n.transpose(1, 0, 2)
+    if dtype == torch.float32:
+        want_seq, want_pooled, t = g['sequence'], g['pooled'], 1e-5
+    else:
+        want_seq, want_pooled = bert_from_ids({k: prep(v, dtype) for k, v in p.items()}, g['ids'],
+                                              g['token_types'], vl, NL, H)
+        t = 2e-2 * 1.5
+    for b in range(len(vl)):
+        assert rel_err(seq_n[b, :vl[b]], want_seq[b, :vl[b]]) < t, b
+        assert (seq_n[b, vl[b]:] == 0).all()
+    assert rel_err(to_np(pooled), want_pooled) < t

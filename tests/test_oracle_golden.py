@@ -385,3 +385,33 @@ def test_t5_encoder_decoder_against_hf_goldens(name):
     for b in range(len(svl)):
         assert_allclose(enc[b, :svl[b]], g['enc_out'][b, :svl[b]], rtol=0, atol=5e-6)
         assert_allclose(dec[b, :tvl[b]], g['dec_out'][b, :tvl[b]], rtol=0, atol=5e-6)
+
+
+def bert_from_ids(p, ids, token_types, valid_length, num_layers, num_heads):
+    """ids -> (sequence, pooled) with the oracle's pieces, parameters under the reference's names
+    (models/bert.py:404-456)."""
+    emb = ref.initial_embedding(ids, token_types, p['word_embed.weight'],
+                                p['token_type_embed.weight'], p['token_pos_embed._embed.weight'],
+                                {'gamma': p['embed_layer_norm.gamma'],
+                                 'beta': p['embed_layer_norm.beta']}, eps=1e-12)
+    layers = [ref._sub(p, 'encoder.all_layers.{}.'.format(i)) for i in range(num_layers)]
+    seq, _ = ref.bert_transformer(emb, valid_length, layers, num_heads, 1e-12, 'gelu')
+    return seq, ref.apply_pooling(seq, p['pooler.weight'], p['pooler.bias'])
+
+
+@pytest.mark.parametrize('name', ['bert_hf_d64', 'bert_hf_h4'])
+def test_bert_backbone_against_hf_goldens(name):
+    """ids -> contextual embeddings -> pooled output of the oracle against HuggingFace's BertModel
+    in float64 (oracle/gen_golden_bert_hf.py: the reference converter's renaming of the TF layout
+    composed with HF's).  Pins the embedding front-end, the packed-QKV convention, erf-GELU, both
+    LayerNorms and the pooler in one known-answer check.  Valid positions only: HF masks keys, the
+    reference also masks padded query rows and zeroes them (models/bert.py:311-312)."""
+    g = load(name + '.npz')
+    p = {k[2:]: g[k] for k in g.files if k.startswith('p:')}
+    vl = g['valid_length']
+    seq, pooled = bert_from_ids(p, g['ids'], g['token_types'], vl, int(g['num_layers']),
+                                int(g['num_heads']))
+    for b in range(len(vl)):
+        assert_allclose(seq[b, :vl[b]], g['sequence'][b, :vl[b]], rtol=0, atol=1e-10)
+        assert (seq[b, vl[b]:] == 0).all()
+    assert_allclose(pooled, g['pooled'], rtol=0, atol=1e-10)
