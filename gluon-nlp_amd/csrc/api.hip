@@ -525,6 +525,37 @@ int gnlp_bucket_embedding(void *out, const void *weight, const int32_t *rel, int
   return check_launch("gnlp_bucket_embedding");
 }
 
+int gnlp_sinusoidal_embedding(void *out, const float *positions, const float *base_mult, int dtype,
+                              int64_t n, int64_t units, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "dtype=%d", dtype);
+  REQUIRE(n >= 0 && units >= 0, "n=%lld units=%lld", (long long)n, (long long)units);
+  if (n * units == 0) return GNLP_OK;
+  REQUIRE(out && positions, "null out / positions");
+  REQUIRE(units < 2 || base_mult, "null base_mult");
+  launch_sinusoid(out, positions, base_mult, dtype, n, units, S(stream));
+  return check_launch("gnlp_sinusoidal_embedding");
+}
+
+int gnlp_rel_attn_score(void *out, const void *query, const int64_t *q_stride,
+                        const void *pos_embed, const int32_t *rel_positions, int dtype, int64_t B,
+                        int64_t H, int64_t Lq, int64_t Lm, int64_t C, int64_t R, int32_t clip_lo,
+                        int32_t clip_hi, int32_t base, int wrap, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "dtype=%d", dtype);
+  REQUIRE(B >= 0 && H >= 0 && Lq >= 0 && Lm >= 0 && C >= 0, "negative extent");
+  if (B * H * Lq * Lm == 0) return GNLP_OK;
+  REQUIRE(out && query && q_stride && pos_embed && rel_positions, "null argument");
+  REQUIRE(R >= 1, "empty position table (R=%lld)", (long long)R);
+  REQUIRE(clip_lo <= clip_hi, "clip range [%d, %d]", clip_lo, clip_hi);
+  REQUIRE(C <= 8192, "head units %lld > 8192", (long long)C);
+  REQUIRE(B * H * Lq <= 0x7fffffffLL, "B*H*Lq=%lld exceeds the grid limit", (long long)(B * H * Lq));
+  RelScoreArgs a;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lm = Lm; a.C = C; a.R = R;
+  for (int i = 0; i < 3; ++i) a.qs[i] = q_stride[i];
+  a.lo = clip_lo; a.hi = clip_hi; a.base = base; a.wrap = wrap ? 1 : 0;
+  launch_rel_score(out, query, pos_embed, rel_positions, dtype, a, S(stream));
+  return check_launch("gnlp_rel_attn_score");
+}
+
 int gnlp_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq, int64_t Lm,
                      int bidirectional, int num_buckets, int max_distance, gnlp_stream_t stream) {
   REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);

@@ -34,6 +34,19 @@ struct BucketTable {
   int thr[128];    // thr[q] = smallest n whose (unclipped) bucket is >= max_exact + q + 1
 };
 
+// relscore.hip
+struct RelScoreArgs {
+  int64_t B, H, Lq, Lm, C, R;
+  int64_t qs[3];        // query strides in elements for (batch, head, time)
+  int lo, hi;           // clip range of the relative positions (INT_MIN / INT_MAX: none)
+  int base;             // table row of relative position `base` is row 0
+  int wrap;             // negative indices wrap by R (np.take mode='wrap')
+};
+void launch_rel_score(void *out, const void *q, const void *emb, const int32_t *rel, int dtype,
+                      const RelScoreArgs &a, hipStream_t s);
+void launch_sinusoid(void *out, const float *pos, const float *base, int dtype, int64_t n,
+                     int64_t units, hipStream_t s);
+
 // elementwise.hip
 void launch_self_mask(uint8_t *mask, const void *vl, int vl_dtype, int64_t B, int64_t L,
                       int attn_type, hipStream_t s);

@@ -98,6 +98,11 @@ PROTOTYPES = {
                                       c_int, c_int, c_int, c_void_p]),
     'gnlp_t5_rel_bias': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int,
                                  c_int, c_int, c_void_p]),
+    'gnlp_sinusoidal_embedding': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
+                                          c_void_p]),
+    'gnlp_rel_attn_score': (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int,
+                                    c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int32,
+                                    c_int32, c_int32, c_int, c_void_p]),
     'gnlp_ffn_workspace_bytes': (c_size_t, [POINTER(FfnCfg), c_int64]),
     'gnlp_positionwise_ffn': (c_int, [c_void_p, c_void_p, POINTER(FfnParams), POINTER(FfnCfg),
                                       c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p,

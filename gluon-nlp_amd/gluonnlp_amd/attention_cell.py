@@ -307,16 +307,17 @@ def gen_rel_position(data, past_data=None, dtype=None, layout='NT'):
 
 
 class RelAttentionScoreCell(torch.nn.Module):
-    """Relative-position score cell.  attention_cell.py:659-881.  Only ``method='t5'`` (the
-    encoder path of BASELINE config 4) is implemented; 'transformer_xl' / 'shaw' are listed as
-    "next" in SURVEY.md §8(f) and raise NotImplementedError."""
+    """Relative-position score cell.  attention_cell.py:659-881: 't5' (bucketed bias, the encoder
+    path of BASELINE config 4), 'transformer_xl' (<Q, W S_{i-j}>, sinusoidal S) and 'shaw'
+    (<Q, E_{i-j}>, learned E)."""
 
     def __init__(self, query_units, num_heads, pos_embed_units: Optional[int] = None,
                  max_distance=None, bidirectional=False, num_buckets=None, method='transformer_xl',
                  dropout: float = 0.0, dtype='float32', layout='NTK', use_einsum=False,
                  embed_initializer=None):
         super().__init__()
-        from .layers import BucketPositionalEmbedding
+        from .layers import (BucketPositionalEmbedding, Dense, LearnedPositionalEmbedding,
+                             SinusoidalPositionalEmbedding)
         self._dropout = dropout
         self._method = method
         self._query_units = query_units
@@ -332,7 +333,27 @@ class RelAttentionScoreCell(torch.nn.Module):
         self._layout = layout
         if self._layout not in ['NKT', 'NTK', 'TNK']:
             raise ValueError('layout="{}" is not supported'.format(self._layout))
-        if method == 't5':
+        if method == 'transformer_xl':
+            if pos_embed_units is None:
+                pos_embed_units = self._num_heads * self._head_query_units
+            self._rel_pos_embed = SinusoidalPositionalEmbedding(units=pos_embed_units,
+                                                                dtype=self._dtype)
+            self._rel_proj = Dense(units=query_units, in_units=pos_embed_units, flatten=False,
+                                   use_bias=False, dtype=self._dtype)
+        elif method == 'shaw':
+            assert self._max_distance is not None, 'Must set max_distance when method="shaw".'
+            if self._bidirectional:
+                vocab_size = self._max_distance * 2 + 1
+            else:
+                vocab_size = self._max_distance + 1
+
+            def xavier_in(t):        # Xavier(gaussian, factor_type='in', magnitude=1)
+                t.normal_(0.0, (1.0 / t.shape[1]) ** 0.5)
+            self._rel_pos_embed = LearnedPositionalEmbedding(
+                units=self._num_heads * self._head_query_units, max_length=vocab_size,
+                weight_initializer=xavier_in, mode='wrap' if self._bidirectional else 'raise',
+                dtype=self._dtype)
+        elif method == 't5':
             if self._num_buckets is None:
                 self._num_buckets = 32
             if self._max_distance is None:
@@ -341,9 +362,6 @@ class RelAttentionScoreCell(torch.nn.Module):
                 units=num_heads, num_buckets=self._num_buckets, max_distance=self._max_distance,
                 bidirectional=self._bidirectional, embed_initializer=embed_initializer,
                 dtype=self._dtype)
-        elif method in ('transformer_xl', 'shaw'):
-            raise NotImplementedError('method="{}" is outside the encoder hot path of this build '
-                                      '(SURVEY.md §8f)'.format(method))
         else:
             raise NotImplementedError('method="{}" is currently not supported!'.format(method))
 
@@ -363,6 +381,47 @@ class RelAttentionScoreCell(torch.nn.Module):
         return out
 
     def forward(self, rel_positions, query=None):
-        """rel_positions (Lq, Lm) int32 -> (num_heads, Lq, Lm).  attention_cell.py:876-878."""
-        emb = self._rel_pos_embed(rel_positions)          # (Lq, Lm, H)
-        return emb.permute(2, 0, 1).contiguous()
+        """rel_positions (Lq, Lm) -> 't5': (num_heads, Lq, Lm); 'transformer_xl' / 'shaw' (need
+        ``query`` in the cell's layout): (batch, num_heads, Lq, Lm).  attention_cell.py:796-881."""
+        if self._method == 't5':
+            emb = self._rel_pos_embed(rel_positions)          # (Lq, Lm, H)   :876-878
+            return emb.permute(2, 0, 1).contiguous()
+        assert query is not None, 'Must specify query if method={}'.format(self._method)
+        rel = T.as_tensor(rel_positions)
+        q = _inner_contig(T.as_tensor(query))
+        dev = T.require_device(rel, q)
+        rel = rel.to(torch.int32).contiguous()
+        Lq, Lm = rel.shape
+        B, H, Lq2 = _bht_shape(q, self._layout)
+        if Lq2 != Lq or H != self._num_heads or q.shape[-1] != self._head_query_units:
+            raise ValueError('query {} does not match rel_positions {} / the cell ({} heads of {})'
+                             .format(tuple(q.shape), tuple(rel.shape), self._num_heads,
+                                     self._head_query_units))
+        lo, hi = -2 ** 31, 2 ** 31 - 1
+        if self._max_distance is not None:                    # :818-825
+            lo, hi = (-self._max_distance if self._bidirectional else 0), self._max_distance
+        if self._method == 'shaw':
+            # the learned table itself: row = clipped position, negatives wrap (np.take 'wrap')
+            table, base, wrap = self._rel_pos_embed.weight.data, 0, int(self._bidirectional)
+        else:
+            # 'transformer_xl': project the sinusoids of every position in the (clipped) range
+            if self._max_distance is not None:
+                p_lo, p_hi = lo, hi
+            elif rel.numel():
+                mn, mx = torch.aminmax(rel)
+                p_lo, p_hi = int(mn), int(mx)
+            else:
+                p_lo = p_hi = 0
+            positions = torch.arange(p_lo, p_hi + 1, dtype=torch.float32, device=dev)
+            table = T.as_tensor(self._rel_proj(self._rel_pos_embed(positions)))   # :829-831
+            base, wrap = p_lo, 0
+        if table.dtype != q.dtype:
+            raise TypeError('query dtype {} != position embedding dtype {}'.format(q.dtype,
+                                                                                  table.dtype))
+        table = table.contiguous()
+        out = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev)
+        _lib.check(_lib.load().gnlp_rel_attn_score(
+            T.ptr(out), T.ptr(q), (ctypes.c_int64 * 3)(*_bht_strides(q, self._layout)),
+            T.ptr(table), T.ptr(rel), T.code(q), B, H, Lq, Lm, self._head_query_units,
+            table.shape[0], lo, hi, base, wrap, T.stream(dev)))
+        return T.like_caller(out, query)

@@ -271,14 +271,47 @@ class Embedding(nn.Module):
         return embedding_forward(ids, None, self.weight.data, None, None, None, None, 0.0, 'NT')
 
 
+class SinusoidalPositionalEmbedding(nn.Module):
+    """layers.py:405-456: a geometric sequence of timescales; ``base_mult`` is the reference's
+    Constant of the same name (float32, computed the way ``_init_sinusoidal_base`` does)."""
+
+    def __init__(self, units: int, dtype='float32'):
+        super().__init__()
+        import numpy as np
+        self._units = units
+        self._dtype = dtype
+        half_units = units // 2
+        with np.errstate(divide='ignore', invalid='ignore'):
+            val = np.log(10000) / (half_units - 1)
+            base = np.exp(np.arange(half_units, dtype=np.float32) * -val)
+        self.register_buffer('base_mult', torch.from_numpy(base.astype(np.float32)))
+
+    def forward(self, positions):
+        """positions (...,) -> (..., units)."""
+        pos = T.as_tensor(positions)
+        base = self.base_mult.to(torch.float32)     # a module-wide .to(dtype) must not narrow it
+        dev = T.require_device(pos, base)
+        p32 = pos.to(torch.float32).contiguous()
+        dt = T.torch_dtype(self._dtype)
+        out = torch.empty(tuple(pos.shape) + (self._units,), dtype=dt, device=dev)
+        _lib.check(_lib.load().gnlp_sinusoidal_embedding(
+            T.ptr(out), T.ptr(p32), T.ptr(base), T.code(out), p32.numel(), self._units,
+            T.stream(dev)))
+        return T.like_caller(out, positions)
+
+    def __repr__(self):
+        return '{}(units={}, dtype={})'.format(self.__class__.__name__, self._units, self._dtype)
+
+
 class LearnedPositionalEmbedding(nn.Module):
-    """layers.py:460-482: a (max_length, units) table read with np.take(mode='clip')."""
+    """layers.py:460-482: a (max_length, units) table read with np.take(mode=...)."""
 
     def __init__(self, units, max_length, mode='clip', dtype='float32', weight_initializer=None):
         super().__init__()
-        if mode != 'clip':
+        if mode not in ('clip', 'wrap', 'raise'):
             raise NotImplementedError('mode={} is not supported'.format(mode))
         self._units, self._max_length, self._mode = units, max_length, mode
+        self._dtype = dtype
         self.weight = _empty_param((max_length, units), dtype)
         with torch.no_grad():
             if callable(weight_initializer):
@@ -286,17 +319,53 @@ class LearnedPositionalEmbedding(nn.Module):
             else:
                 trunc_norm_(self.weight.data, 0.02)
 
+    def forward(self, positions):
+        """positions (...,) integer -> (..., units): np.take(weight, positions, axis=0, mode)."""
+        pos = T.as_tensor(positions)
+        if pos.dtype not in (torch.int32, torch.int64):
+            pos = pos.to(torch.int64)
+        if self._mode == 'wrap':
+            pos = torch.remainder(pos, self._max_length)
+        elif self._mode == 'raise':
+            if pos.numel() and bool(((pos < -self._max_length) | (pos >= self._max_length)).any()):
+                raise IndexError('position index out of range for a table of {} rows'.format(
+                    self._max_length))
+            pos = torch.where(pos < 0, pos + self._max_length, pos)   # python-style negatives
+        out = embedding_forward(pos.reshape(1, -1), None, self.weight.data, None, None, None, None,
+                                0.0, 'NT')
+        return T.like_caller(T.as_tensor(out).reshape(tuple(pos.shape) + (self._units,)), positions)
+
+    def __repr__(self):
+        return '{}(units={}, max_length={}, mode={}, dtype={})'.format(
+            self.__class__.__name__, self._units, self._max_length, self._mode, self._dtype)
+
 
 class PositionalEmbedding(nn.Module):
-    """layers.py:370-401.  Only method='learned' (what BERT / RoBERTa / ELECTRA use) is built;
-    the table lives at ``_embed.weight`` as in the reference."""
+    """layers.py:370-401; the table / constants live under ``_embed`` as in the reference."""
 
     def __init__(self, units, max_length=None, method='sinusoidal', dtype='float32'):
         super().__init__()
-        if method != 'learned':
-            raise NotImplementedError('method={} is not supported (learned is)'.format(method))
         self._units, self._max_length, self._method = units, max_length, method
-        self._embed = LearnedPositionalEmbedding(units=units, max_length=max_length, dtype=dtype)
+        self._dtype = dtype
+        if method == 'sinusoidal':
+            self._embed = SinusoidalPositionalEmbedding(units=units, dtype=dtype)
+        elif method == 'learned':
+            self._embed = LearnedPositionalEmbedding(units=units, max_length=max_length,
+                                                     dtype=dtype)
+        else:
+            raise NotImplementedError
+
+    def forward(self, positions):
+        return self._embed(positions)
+
+    def table(self, inputs, layout):
+        """Rows 0 .. L-1 of the position embedding for the fused front-end kernel: the learned
+        table itself, or the sinusoids of arange(L) (what ``self(arange_like(inputs))`` is)."""
+        if self._method == 'learned':
+            return self._embed.weight.data
+        ids = T.as_tensor(inputs)
+        L = ids.shape[1 if layout == 'NT' else 0]
+        return T.as_tensor(self._embed(torch.arange(L, device=ids.device)))
 
 
 def embedding_forward(inputs, token_types, word_w, type_w, pos_w, ln_gamma, ln_beta, eps, layout):

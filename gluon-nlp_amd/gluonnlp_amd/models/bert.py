@@ -151,7 +151,8 @@ class BertModel(nn.Module):
 
     def get_initial_embedding(self, inputs, token_types=None):
         """models/bert.py:458-504 (one kernel: three gathers, two adds, LayerNorm)."""
-        pos_w = self.token_pos_embed._embed.weight.data if self.pos_embed_type is not None else None
+        pos_w = (self.token_pos_embed.table(inputs, self._layout)
+                 if self.pos_embed_type is not None else None)
         return embedding_forward(inputs, token_types, self.word_embed.weight.data,
                                  self.token_type_embed.weight.data, pos_w,
                                  self.embed_layer_norm.gamma.data, self.embed_layer_norm.beta.data,

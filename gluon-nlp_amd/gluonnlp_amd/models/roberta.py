@@ -100,7 +100,7 @@ class RobertaModel(nn.Module):
     def get_initial_embedding(self, inputs):
         """models/roberta.py:337-372: no token types; LayerNorm only with
         encoder_normalize_before."""
-        pos_w = self.pos_embed._embed.weight.data if self.pos_embed_type else None
+        pos_w = self.pos_embed.table(inputs, self._layout) if self.pos_embed_type else None
         g = self.embed_ln.gamma.data if self.encoder_normalize_before else None
         b = self.embed_ln.beta.data if self.encoder_normalize_before else None
         return embedding_forward(inputs, None, self.word_embed.weight.data, None, pos_w, g, b,

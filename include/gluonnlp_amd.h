@@ -194,6 +194,24 @@ int gnlp_bucket_embedding(void *out, const void *weight, const int32_t *rel, int
 int gnlp_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq, int64_t Lm,
                      int bidirectional, int num_buckets, int max_distance, gnlp_stream_t stream);
 
+/* SinusoidalPositionalEmbedding.forward   layers.py:429-450: out (n, units) =
+ * concat(sin(p * base_mult), cos(p * base_mult) [, 0 when units is odd]); positions float32 (n),
+ * base_mult float32 (units / 2) = exp(arange(units/2) * -log(10000) / (units/2 - 1)) (:418-422). */
+int gnlp_sinusoidal_embedding(void *out, const float *positions, const float *base_mult, int dtype,
+                              int64_t n, int64_t units, gnlp_stream_t stream);
+
+/* RelAttentionScoreCell(method='transformer_xl' | 'shaw').forward   attention_cell.py:816-875:
+ * out (B, H, Lq, Lm), out[b,h,i,j] = <query[b,h,i,:], pos_embed[idx(rel[i,j]), h, :]> with
+ * idx(r) = clip(r, clip_lo, clip_hi) - base (+ R when negative and `wrap`, np.take mode='wrap').
+ * query: C contiguous, q_stride = element strides of (batch, head, time) -- NKT / NTK / TNK are
+ * stride descriptors; pos_embed (R, H, C) contiguous = the (projected) embeddings of relative
+ * positions base .. base + R - 1 ('transformer_xl') or the learned table itself ('shaw');
+ * rel_positions (Lq, Lm) int32.  Replaces unique + matmul + gather_nd (:827-875) by one kernel. */
+int gnlp_rel_attn_score(void *out, const void *query, const int64_t *q_stride,
+                        const void *pos_embed, const int32_t *rel_positions, int dtype, int64_t B,
+                        int64_t H, int64_t Lq, int64_t Lm, int64_t C, int64_t R, int32_t clip_lo,
+                        int32_t clip_hi, int32_t base, int wrap, gnlp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole blocks (one C call launches every kernel of the block on `stream`)
  * ------------------------------------------------------------------------------------------- */

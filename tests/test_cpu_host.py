@@ -168,8 +168,10 @@ def test_parameter_names_match_reference():
                   'embed_layer_norm.gamma', 'embed_layer_norm.beta',
                   'embed_factorized_proj.weight', 'embed_factorized_proj.bias'}
     assert 'embed_factorized_proj.weight' not in ElectraModel(embed_size=8, **kw).state_dict()
+    sin = BertModel(pos_embed_type='sinusoidal', **kw).state_dict()       # layers.py:378-380
+    assert 'token_pos_embed._embed.base_mult' in sin and 'token_pos_embed._embed.weight' not in sin
     with pytest.raises(NotImplementedError):
-        BertModel(pos_embed_type='sinusoidal', **kw)
+        BertModel(pos_embed_type='rotary', **kw)
     m = BertTransformer(units=8, hidden_size=16, num_layers=1, num_heads=2)
     assert m.all_layers[0].attn_qkv.weight.shape == (24, 8)      # (3U, U): Q | K | V thirds
     assert m.all_layers[0].ffn.ffn_1.weight.shape == (16, 8)

@@ -1,0 +1,113 @@
+"""RelAttentionScoreCell 'transformer_xl' / 'shaw', Sinusoidal / Learned positional embeddings on
+the MI355X (forward; attention_cell.py:659-881, layers.py:370-482) through the
+C ABI, against the oracle; the reference test's properties (tests/test_attention_cell.py:272-391)
+are checked on the device results themselves."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref
+from tests.util import prep, rel_err, to_dev, to_np, tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nlp():
+    import gluonnlp_amd
+    from gluonnlp_amd import _lib
+    _lib.load()
+    return gluonnlp_amd
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('units', [16, 33, 64])
+def test_sinusoidal_embedding(nlp, dtype, units):
+    from gluonnlp_amd.layers import PositionalEmbedding
+    dn = 'float32' if dtype == torch.float32 else 'bfloat16'
+    m = PositionalEmbedding(units=units, method='sinusoidal', dtype=dn).cuda()
+    pos = np.concatenate([np.arange(-40, 600), [2047, -2047]]).reshape(2, -1)
+    got = m(torch.from_numpy(pos).cuda())
+    assert tuple(got.shape) == pos.shape + (units,) and got.dtype == dtype
+    want = ref.sinusoidal_positional_embedding(pos, units)
+    # device sinf / cosf on the same float32 argument: a few ulp of 1.0
+    assert np.abs(to_np(got) - want).max() < (2e-6 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize('mode', ['clip', 'wrap', 'raise'])
+def test_learned_positional_embedding_modes(nlp, mode):
+    from gluonnlp_amd.layers import LearnedPositionalEmbedding
+    rng = np.random.default_rng(3)
+    m = LearnedPositionalEmbedding(units=24, max_length=11, mode=mode).cuda()
+    w = rng.standard_normal((11, 24)).astype(np.float32)
+    m.weight.data = to_dev(w)
+    pos = np.array([[0, 10, 5], [-1, -11, 3]]) if mode != 'clip' else np.array([[0, 10, 50], [-1, -11, 3]])
+    if mode == 'wrap':
+        pos = np.array([[0, 10, 50], [-1, -23, 3]])
+    got = m(torch.from_numpy(pos).cuda())
+    assert torch.equal(got.cpu(), torch.from_numpy(ref.learned_positional_embedding(w, pos, mode)))
+    if mode == 'raise':
+        with pytest.raises(IndexError):
+            m(torch.tensor([11]).cuda())
+
+
+CASES = [('transformer_xl', False, None), ('transformer_xl', True, 6), ('shaw', False, 20),
+         ('shaw', True, 5)]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['NKT', 'NTK', 'TNK'])
+@pytest.mark.parametrize('method,bidirectional,max_distance', CASES)
+def test_rel_attention_score(nlp, method, bidirectional, max_distance, layout, dtype):
+    from gluonnlp_amd.attention_cell import RelAttentionScoreCell
+    rng = np.random.default_rng(9)
+    B, H, Lq, Lm, C = 3, 4, 20, 37, 16          # shapes of tests/test_attention_cell.py:276-281 scaled
+    dn = 'float32' if dtype == torch.float32 else 'bfloat16'
+    cell = RelAttentionScoreCell(query_units=H * C, num_heads=H, method=method,
+                                 bidirectional=bidirectional, max_distance=max_distance,
+                                 layout=layout, dtype=dn).cuda()
+    kw = dict(method=method, num_heads=H, max_distance=max_distance, bidirectional=bidirectional)
+    if method == 'transformer_xl':
+        w = (0.3 * rng.standard_normal((H * C, H * C))).astype(np.float32)
+        cell._rel_proj.weight.data = to_dev(w, dtype)
+        kw['rel_proj_weight'] = prep(w, dtype)
+    else:
+        vocab = (2 * max_distance + 1) if bidirectional else (max_distance + 1)
+        w = rng.standard_normal((vocab, H * C)).astype(np.float32)
+        cell._rel_pos_embed.weight.data = to_dev(w, dtype)
+        kw['shaw_weight'] = prep(w, dtype)
+    q = rng.standard_normal((B, H, Lq, C))
+    rel = np.arange(Lq)[:, None] - np.arange(Lm)[None, :]
+    perm = {'NKT': (0, 1, 2, 3), 'NTK': (0, 2, 1, 3), 'TNK': (2, 0, 1, 3)}[layout]
+    qd = to_dev(q, dtype).permute(*perm).contiguous()
+    reld = torch.from_numpy(rel.astype(np.int32)).cuda()
+    got = cell(reld, qd)
+    assert tuple(got.shape) == (B, H, Lq, Lm) and got.dtype == dtype
+    want = ref.rel_attention_score(prep(q, dtype), rel, layout='NKT', **kw)
+    # transformer_xl in bf16: the sinusoid table and its projection are rounded to bf16 on the
+    # device (as the reference's dtype=bf16 cell would), not in the float64 oracle
+    t = tol(dtype) * (2 if (dtype == torch.bfloat16 and method == 'transformer_xl') else 1)
+    assert rel_err(to_np(got), want) < t
+    # permutation equivariance on the device (tests/test_attention_cell.py:332-355)
+    qp = torch.from_numpy(rng.permutation(Lq)).cuda()
+    mp = torch.from_numpy(rng.permutation(Lm)).cuda()
+    q_nkt = to_dev(q, dtype)[:, :, qp, :]
+    got_p = cell(reld[qp][:, mp].contiguous(), q_nkt.permute(*perm).contiguous())
+    assert torch.equal(got_p, got[:, :, qp][:, :, :, mp])
+    # strided query (a view of a packed buffer) gives the same bits: layouts are strides
+    packed = torch.zeros(qd.shape[:-1] + (3 * C,), dtype=dtype, device='cuda')
+    packed[..., C:2 * C] = qd
+    assert torch.equal(cell(reld, packed[..., C:2 * C]), got)
+
+
+def test_rel_attention_score_errors(nlp):
+    from gluonnlp_amd.attention_cell import RelAttentionScoreCell
+    with pytest.raises(AssertionError):
+        RelAttentionScoreCell(query_units=16, num_heads=4, method='shaw')      # needs max_distance
+    with pytest.raises(NotImplementedError):
+        RelAttentionScoreCell(query_units=16, num_heads=4, method='nope')
+    with pytest.raises(ValueError):
+        RelAttentionScoreCell(query_units=16, num_heads=4, layout='KNT')
+    cell = RelAttentionScoreCell(query_units=16, num_heads=4, method='transformer_xl').cuda()
+    with pytest.raises(AssertionError):
+        cell(torch.zeros((2, 2), dtype=torch.int32, device='cuda'))           # query is required

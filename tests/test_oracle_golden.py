@@ -415,3 +415,61 @@ def test_bert_backbone_against_hf_goldens(name):
         assert_allclose(seq[b, :vl[b]], g['sequence'][b, :vl[b]], rtol=0, atol=1e-10)
         assert (seq[b, vl[b]:] == 0).all()
     assert_allclose(pooled, g['pooled'], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize('method,bidirectional,max_distance', [
+    ('transformer_xl', False, None), ('transformer_xl', True, 6), ('shaw', False, 20),
+    ('shaw', True, 5)])
+def test_rel_attention_score_restatement(method, bidirectional, max_distance):
+    """'transformer_xl' / 'shaw' scores of the oracle (the reference's unique + matmul + gather
+    text) against an independent per-element formulation R[b,h,i,j] = <Q[b,h,i], E[rel(i,j)][h]>
+    (the docstring formula, attention_cell.py:678-689), plus the reference test's properties:
+    permutation equivariance and 3-way layout agreement (tests/test_attention_cell.py:332-389).
+    No known-answer vectors exist for these methods in the reference: parity unpinned beyond that."""
+    rng = np.random.default_rng(5)
+    B, H, Lq, Lm, C = 2, 3, 7, 9, 4
+    q = rng.standard_normal((B, H, Lq, C))
+    rel = np.arange(Lq)[:, None] - np.arange(Lm)[None, :]      # as the reference test builds it
+    kw = dict(method=method, num_heads=H, max_distance=max_distance, bidirectional=bidirectional)
+    if method == 'transformer_xl':
+        kw['rel_proj_weight'] = rng.standard_normal((H * C, H * C))
+    else:
+        vocab = (2 * max_distance + 1) if bidirectional else (max_distance + 1)
+        kw['shaw_weight'] = rng.standard_normal((vocab, H * C))
+    got = ref.rel_attention_score(q, rel, layout='NKT', **kw)
+    assert got.shape == (B, H, Lq, Lm)
+    want = np.zeros_like(got)
+    for i in range(Lq):
+        for j in range(Lm):
+            r = rel[i, j]
+            if max_distance is not None:
+                r = int(np.clip(r, -max_distance if bidirectional else 0, max_distance))
+            if method == 'transformer_xl':
+                e = ref.sinusoidal_positional_embedding(np.array([r]), H * C)[0] @ kw['rel_proj_weight'].T
+            else:
+                e = kw['shaw_weight'][r % kw['shaw_weight'].shape[0]]
+            want[:, :, i, j] = np.einsum('bhc,hc->bh', q[:, :, i, :], e.reshape(H, C))
+    assert_allclose(got, want, rtol=0, atol=1e-12)
+    qp, mp = rng.permutation(Lq), rng.permutation(Lm)
+    perm = ref.rel_attention_score(q[:, :, qp, :], rel[qp][:, mp], layout='NKT', **kw)
+    assert_allclose(perm, got[:, :, qp][:, :, :, mp], rtol=0, atol=1e-12)
+    assert_allclose(ref.rel_attention_score(q.transpose(0, 2, 1, 3), rel, layout='NTK', **kw), got,
+                    rtol=0, atol=1e-12)
+    assert_allclose(ref.rel_attention_score(q.transpose(2, 0, 1, 3), rel, layout='TNK', **kw), got,
+                    rtol=0, atol=1e-12)
+
+
+def test_sinusoidal_embedding_restatement():
+    """layers.py:405-450 against torch's float64 sin / cos of the same float32 arguments; odd
+    units get the zero column."""
+    import torch
+    pos = np.array([0, 1, 2, 17, 511, -3])
+    for units in (8, 9):
+        got = ref.sinusoidal_positional_embedding(pos, units)
+        half = units // 2
+        base = np.exp(np.arange(half, dtype=np.float32) * -(np.log(10000) / (half - 1))).astype(np.float32)
+        arg = torch.from_numpy((pos.astype(np.float32)[:, None] * base).astype(np.float32)).double()
+        want = torch.cat([torch.sin(arg), torch.cos(arg)] +
+                         ([torch.zeros(len(pos), 1, dtype=torch.float64)] if units % 2 else []), -1)
+        assert got.shape == (len(pos), units)
+        assert_allclose(got, want.numpy(), rtol=0, atol=1e-15)
