@@ -89,20 +89,44 @@ attn_fwd_bf16_d64(FusedAttn a) {
   const int srow = lane >> 3, cpos = lane & 7;
   const bf16 *kbase = (const bf16 *)a.k + b * a.ks[0] + h * a.ks[1];
   const bf16 *vbase = (const bf16 *)a.v + b * a.vs[0] + h * a.vs[1];
-  auto stage = [&](int buf, int tile) {
+  // Lane pointers of tile 0; a full tile adds a uniform offset (scalar ALU) -- the per-lane
+  // 64-bit row * stride products cost 74 of the 248 vector-ALU issue slots per tile (PMC +
+  // disassembly) -- only the last, partial tile recomputes clamped rows.
+  const bf16 *kp0[2], *vp0[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int piece = wave * 2 + t;
-      const int row = piece * 8 + srow;
-      int64_t key = (int64_t)tile * KV_TILE + row;
-      if (key > a.Lm - 1) key = a.Lm - 1;
-      const int ck = cpos ^ ((row >> 1) & 7);          // K image: b128 row reads
-      const int cv = cpos ^ (((row >> 1) & 1) << 2);   // V image: transposed b64 reads
-      __builtin_amdgcn_global_load_lds((gptr_t)(kbase + key * a.ks[2] + ck * 8),
-                                       (lptr_t)(smem + buf * TILE_BYTES + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vbase + key * a.vs[2] + cv * 8),
-                                       (lptr_t)(smem + (2 + buf) * TILE_BYTES + piece * 1024), 16,
-                                       0, 0);
+  for (int t = 0; t < 2; ++t) {
+    const int row = (wave * 2 + t) * 8 + srow;
+    kp0[t] = kbase + row * a.ks[2] + (cpos ^ ((row >> 1) & 7)) * 8;          // K image: b128 row reads
+    vp0[t] = vbase + row * a.vs[2] + (cpos ^ (((row >> 1) & 1) << 2)) * 8;   // V image: transposed b64 reads
+  }
+  auto stage = [&](int buf, int tile) {
+    const int64_t adv = (int64_t)tile * KV_TILE;           // uniform
+    if (adv + KV_TILE <= a.Lm) {
+      const int64_t kstep = adv * a.ks[2], vstep = adv * a.vs[2];   // uniform
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int piece = wave * 2 + t;
+        __builtin_amdgcn_global_load_lds((gptr_t)(kp0[t] + kstep),
+                                         (lptr_t)(smem + buf * TILE_BYTES + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vp0[t] + vstep),
+                                         (lptr_t)(smem + (2 + buf) * TILE_BYTES + piece * 1024), 16,
+                                         0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int piece = wave * 2 + t;
+        const int row = piece * 8 + srow;
+        int64_t key = adv + row;
+        if (key > a.Lm - 1) key = a.Lm - 1;
+        const int ck = cpos ^ ((row >> 1) & 7);
+        const int cv = cpos ^ (((row >> 1) & 1) << 2);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + key * a.ks[2] + ck * 8),
+                                         (lptr_t)(smem + buf * TILE_BYTES + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vbase + key * a.vs[2] + cv * 8),
+                                         (lptr_t)(smem + (2 + buf) * TILE_BYTES + piece * 1024), 16,
+                                         0, 0);
+      }
     }
   };
 
@@ -192,7 +216,8 @@ attn_fwd_bf16_d64(FusedAttn a) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) mloc = fmaxf(mloc, fmaxf(sacc[kb][e], sacc[kb][e + 1]));
+      for (int e = 0; e < 16; e += 2)            // fmax(fmax(m, a), b) = one v_max3_f32
+        mloc = fmaxf(fmaxf(mloc, sacc[kb][e]), sacc[kb][e + 1]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mz = mloc > -1.0e29f ? mloc * c_scale : NEG_BIG;   // scaled units
     if (__any(mz > m_run + RESCALE_THR)) {                          // wave-uniform

@@ -225,7 +225,7 @@ def test_rel_position_and_t5_bias(nlp):
     assert np.array_equal(e[0, 0], e[0, 1]) and np.array_equal(e[0, 2], e[0, 3])
     assert np.array_equal(e[0, 4], e[0, 5])
     with pytest.raises(NotImplementedError):
-        ac.RelAttentionScoreCell(query_units=8, num_heads=2, method='shaw', max_distance=4)
+        ac.RelAttentionScoreCell(query_units=8, num_heads=2, method='rotary')
 
 
 # ----------------------------------------------------------------------------------- Dense
