@@ -1,12 +1,14 @@
 // C ABI of the MI355X-native encoder forward path (declared in include/gluonnlp_amd.h).
 // Host side only: argument checking, kernel selection, the per-block launch sequences.
 // No allocation, no synchronisation, no global state: everything is enqueued on the caller's
-// HIP stream into caller-owned buffers.
+// HIP stream into caller-owned buffers.  (The one exception is the measurement hook at the end of
+// the dense dispatcher, gnlp_profile_dense_*: off unless a benchmark arms it.)
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
 
 #include "common.h"
@@ -79,8 +81,38 @@ int build_bucket_table(BucketTable *tb, int bidirectional, int num_buckets, int 
   return GNLP_OK;
 }
 
+// ---- measurement hook: HIP events around the dense launches of one (M, N, K) shape -------------
+struct DenseProfile {
+  std::atomic<int> armed{0};
+  int64_t M = 0, N = 0, K = 0;
+  int cap = 0;
+  std::atomic<int> n{0};
+  hipEvent_t *start = nullptr, *stop = nullptr;
+};
+DenseProfile g_prof;
+
 // ---- dense dispatcher --------------------------------------------------------------------------
+int dense_launch(void *out, const void *x, const void *w, const void *bias, const void *other,
+                 int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                 int64_t ldo, int64_t ldother, hipStream_t s);
+
 int dense_impl(void *out, const void *x, const void *w, const void *bias, const void *other,
+               int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
+               int64_t ldo, int64_t ldother, hipStream_t s) {
+  int slot = -1;
+  if (g_prof.armed.load(std::memory_order_acquire) && M == g_prof.M && N == g_prof.N &&
+      K == g_prof.K) {
+    slot = g_prof.n.fetch_add(1);
+    if (slot >= g_prof.cap) slot = -1;
+  }
+  if (slot >= 0) (void)hipEventRecord(g_prof.start[slot], s);
+  const int rc = dense_launch(out, x, w, bias, other, combine, act, dtype, M, N, K, ldx, ldo,
+                              ldother, s);
+  if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], s);
+  return rc;
+}
+
+int dense_launch(void *out, const void *x, const void *w, const void *bias, const void *other,
                int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
                int64_t ldo, int64_t ldother, hipStream_t s) {
   if (M == 0 || N == 0) return GNLP_OK;
@@ -765,6 +797,52 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
                 D, nullptr, 0, 0, 0, 0, s);
   }
   return check_launch("gnlp_t5_encoder_forward");
+}
+
+/* ---- measurement hook (see include/gluonnlp_amd.h) ---- */
+int gnlp_profile_dense_disarm(void) {
+  g_prof.armed.store(0, std::memory_order_release);
+  for (int i = 0; i < g_prof.cap; ++i) {
+    if (g_prof.start) (void)hipEventDestroy(g_prof.start[i]);
+    if (g_prof.stop) (void)hipEventDestroy(g_prof.stop[i]);
+  }
+  delete[] g_prof.start;
+  delete[] g_prof.stop;
+  g_prof.start = g_prof.stop = nullptr;
+  g_prof.cap = 0;
+  g_prof.n.store(0);
+  return GNLP_OK;
+}
+
+int gnlp_profile_dense_arm(int64_t M, int64_t N, int64_t K, int capacity) {
+  REQUIRE(capacity >= 1 && capacity <= 65536, "capacity=%d out of range [1, 65536]", capacity);
+  gnlp_profile_dense_disarm();
+  g_prof.start = new hipEvent_t[capacity];
+  g_prof.stop = new hipEvent_t[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    if (hipEventCreate(&g_prof.start[i]) != hipSuccess || hipEventCreate(&g_prof.stop[i]) != hipSuccess) {
+      g_prof.cap = i;
+      gnlp_profile_dense_disarm();
+      return fail(GNLP_ERR_LAUNCH, "hipEventCreate failed");
+    }
+  }
+  g_prof.cap = capacity;
+  g_prof.M = M; g_prof.N = N; g_prof.K = K;
+  g_prof.n.store(0);
+  g_prof.armed.store(1, std::memory_order_release);
+  return GNLP_OK;
+}
+
+int gnlp_profile_dense_read(float *ms, int capacity) {
+  int n = g_prof.n.load();
+  if (n > g_prof.cap) n = g_prof.cap;
+  if (n > capacity) n = capacity;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess ||
+        hipEventElapsedTime(&ms[i], g_prof.start[i], g_prof.stop[i]) != hipSuccess)
+      return fail(GNLP_ERR_LAUNCH, "reading profile event %d failed", i);
+  }
+  return n;
 }
 
 }  // extern "C"

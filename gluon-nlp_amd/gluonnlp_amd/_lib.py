@@ -103,6 +103,9 @@ PROTOTYPES = {
     'gnlp_rel_attn_score': (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int,
                                     c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int32,
                                     c_int32, c_int32, c_int, c_void_p]),
+    'gnlp_profile_dense_arm': (c_int, [c_int64, c_int64, c_int64, c_int]),
+    'gnlp_profile_dense_read': (c_int, [c_void_p, c_int]),
+    'gnlp_profile_dense_disarm': (c_int, []),
     'gnlp_ffn_workspace_bytes': (c_size_t, [POINTER(FfnCfg), c_int64]),
     'gnlp_positionwise_ffn': (c_int, [c_void_p, c_void_p, POINTER(FfnParams), POINTER(FfnCfg),
                                       c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p,

@@ -300,6 +300,17 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
                             const void *position_bias, void *workspace, size_t workspace_bytes,
                             gnlp_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hook (no counterpart in the reference; for bench.py's roofline object).  While
+ * armed, every dense launch of exactly this (M, N, K) -- from gnlp_dense or from inside the block
+ * / stack entry points -- is bracketed by a pair of HIP events on its own stream, up to `capacity`
+ * launches; gnlp_profile_dense_read waits for the recorded pairs and returns their count, filling
+ * ms[i] with the durations.  Process-global, not for concurrent use; disarm frees the events.
+ * ------------------------------------------------------------------------------------------- */
+int gnlp_profile_dense_arm(int64_t M, int64_t N, int64_t K, int capacity);
+int gnlp_profile_dense_read(float *ms, int capacity);
+int gnlp_profile_dense_disarm(void);
+
 #ifdef __cplusplus
 }
 #endif
