@@ -181,9 +181,10 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
   const size_t need = attn_ws_bytes(d, dtype, scores_out != nullptr, weights_out != nullptr, false);
   REQUIRE(ws_bytes >= need && (need == 0 || ws != nullptr),
           "attention workspace too small: need %zu bytes, got %zu", need, ws_bytes);
-  void *scores = scores_out ? scores_out : (weights_out ? ws : ws);
-  void *weights = weights_out ? weights_out : ws;  // in place over `scores` when both share ws
-  if (!scores_out && !weights_out) { scores = ws; weights = ws; }
+  // whichever of the two the caller does not want lives in the workspace; with neither wanted the
+  // softmax runs in place over the scores
+  void *scores = scores_out ? scores_out : ws;
+  void *weights = weights_out ? weights_out : ws;
   const int64_t LL = d->Lq * d->Lm;
   GenericGemm g;
   memset(&g, 0, sizeof(g));

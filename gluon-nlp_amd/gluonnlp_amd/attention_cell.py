@@ -228,21 +228,18 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
     fused_ok = (not _need_scores and not _need_weights and q.dtype == torch.bfloat16
                 and dk == 64 and dv == 64)
     ws = None if fused_ok else T.workspace(dev, nws)
-    try:
+    rc = lib.gnlp_multi_head_dot_attn(
+        T.ptr(ctx), T.ptr(scores), T.ptr(weights), T.ptr(q), T.ptr(k), T.ptr(v),
+        ctypes.byref(d), T.code(q), mptr, ms, vlp, vlc, eptr, es,
+        0.0 if scale is None else float(scale), T.ptr(ws), 0 if ws is None else ws.numel(),
+        T.stream(dev))
+    if rc != 0 and fused_ok:        # fused kernel declined (alignment): retry with scratch
+        ws = T.workspace(dev, nws)
         rc = lib.gnlp_multi_head_dot_attn(
-            T.ptr(ctx), T.ptr(scores), T.ptr(weights), T.ptr(q), T.ptr(k), T.ptr(v),
-            ctypes.byref(d), T.code(q), mptr, ms, vlp, vlc, eptr, es,
-            0.0 if scale is None else float(scale), T.ptr(ws), 0 if ws is None else ws.numel(),
-            T.stream(dev))
-        if rc != 0 and fused_ok:        # fused kernel declined (alignment): retry with scratch
-            ws = T.workspace(dev, nws)
-            rc = lib.gnlp_multi_head_dot_attn(
-                T.ptr(ctx), None, None, T.ptr(q), T.ptr(k), T.ptr(v), ctypes.byref(d), T.code(q),
-                mptr, ms, vlp, vlc, eptr, es, 0.0 if scale is None else float(scale), T.ptr(ws),
-                ws.numel(), T.stream(dev))
-        _lib.check(rc)
-    finally:
-        pass
+            T.ptr(ctx), None, None, T.ptr(q), T.ptr(k), T.ptr(v), ctypes.byref(d), T.code(q),
+            mptr, ms, vlp, vlc, eptr, es, 0.0 if scale is None else float(scale), T.ptr(ws),
+            ws.numel(), T.stream(dev))
+    _lib.check(rc)
     return (T.like_caller(ctx, query),
             [T.like_caller(scores, query) if scores is not None else None,
              T.like_caller(weights, query) if weights is not None else None])

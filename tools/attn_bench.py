@@ -22,7 +22,8 @@ def run(B, L, H, d=64, bias=False, ragged=False, iters=20):
     ms = s.elapsed_time(t) / iters
     return ms, 4.0 * B * H * L * L * d / ms / 1e9
 
-for name, args in [('bert_large B64 L512', (64, 512, 16)), ('bert_base B256 L128', (256, 128, 12)),
-                   ('t5 B16 L1024 bias', (16, 1024, 12, 64, True)), ('bert_large ragged', (64, 512, 16, 64, False, True))]:
+if __name__ == '__main__':
+  for name, args in [('bert_large B64 L512', (64, 512, 16)), ('bert_base B256 L128', (256, 128, 12)),
+                     ('t5 B16 L1024 bias', (16, 1024, 12, 64, True)), ('bert_large ragged', (64, 512, 16, 64, False, True))]:
     ms, tf = run(*args)
     print('%-22s %.1f us  %.0f TF (dense-equivalent)' % (name, ms * 1e3, tf), flush=True)

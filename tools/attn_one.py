@@ -1,10 +1,9 @@
-import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, 'tools'))
-sys.argv = ['x']
-import importlib.util
-spec = importlib.util.spec_from_file_location('ab', os.path.join(ROOT, 'tools', 'attn_bench.py'))
-src = open(os.path.join(ROOT, 'tools', 'attn_bench.py')).read().split("for name, args in")[0]
-exec(src)
-ms, tf = run(64, 512, 16, iters=3)
+"""One short run of the fused attention kernel at the BERT-large shape (for rocprofv3 --pmc)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import attn_bench  # noqa: E402
+
+ms, tf = attn_bench.run(64, 512, 16, iters=3)
 print('%.1f us %.0f TF' % (ms * 1e3, tf))
