@@ -165,16 +165,24 @@ attn_fwd_bf16_d64(FusedAttn a) {
 
     // ---- S^T = K Q^T : sacc[kb][reg] = score(key = kb*32 + (reg&3) + 8*(reg>>2) + 4*hh, my_q) ----
     f32x16 sacc[2];
+    {
+      bf16x8 kf[4][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.0f;
+        for (int kb = 0; kb < 2; ++kb)
+          kf[s][kb] = *reinterpret_cast<const bf16x8 *>(kt + kb * 4096 + k_off +
+                                                        (((2 * s + hh) ^ k_sw) << 4));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kt + kb * 4096 + k_off +
-                                                      (((2 * s + hh) ^ k_sw) << 4));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
-      }
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][kb], qf[s], sacc[kb], 0, 0, 0);
     }
 
     // ---- bias, mask, online softmax (one query row per lane, keys split with lane^32) ----
