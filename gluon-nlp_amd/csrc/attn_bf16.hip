@@ -226,7 +226,12 @@ attn_fwd_bf16_d64(FusedAttn a) {
 #pragma unroll
       for (int e = 0; e < 16; e += 2)            // fmax(fmax(m, a), b) = one v_max3_f32
         mloc = fmaxf(fmaxf(mloc, sacc[kb][e]), sacc[kb][e + 1]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    {   // lane ^ 32 exchange in the vector ALU (v_permlane32_swap) instead of an LDS round trip
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      const unsigned mu = __builtin_bit_cast(unsigned, mloc);
+      const u32x2 sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+      mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
     const float mz = mloc > -1.0e29f ? mloc * c_scale : NEG_BIG;   // scaled units
     if (__any(mz > m_run + RESCALE_THR)) {                          // wave-uniform
       const float m_new = fmaxf(m_run, mz);
