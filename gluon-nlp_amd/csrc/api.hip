@@ -596,8 +596,24 @@ int gnlp_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_
   int rc = build_bucket_table(&tb, bidirectional, num_buckets, max_distance);
   if (rc) return rc;
   REQUIRE(H >= 0 && Lq >= 0 && Lm >= 0 && ((out && weight) || H * Lq * Lm == 0), "bad arguments");
-  launch_t5_rel_bias(out, weight, dtype, H, Lq, Lm, tb, S(stream));
+  launch_t5_rel_bias(out, weight, dtype, H, Lq, Lm, 0, tb, S(stream));
   return check_launch("gnlp_t5_rel_bias");
+}
+
+int gnlp_t5_rel_bias_table(void *out, const void *weight, int dtype, int64_t H, int64_t Lq,
+                           int64_t Lm, int bidirectional, int num_buckets, int max_distance,
+                           gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(H >= 0 && Lq >= 1 && Lm >= 1, "bad shape");
+  REQUIRE(Lq + Lm < (1LL << 30), "lengths too large");
+  if (H == 0) return GNLP_OK;
+  REQUIRE(out && weight, "NULL tensor");
+  BucketTable tb;
+  int rc = build_bucket_table(&tb, bidirectional, num_buckets, max_distance);
+  if (rc) return rc;
+  // one row per head: entry t holds the bias of relative position t - (Lq - 1)
+  launch_t5_rel_bias(out, weight, dtype, H, 1, Lq + Lm - 1, -(int)(Lq - 1), tb, S(stream));
+  return check_launch("gnlp_t5_rel_bias_table");
 }
 
 size_t gnlp_ffn_workspace_bytes(const gnlp_ffn_cfg *cfg, int64_t rows) {
@@ -776,11 +792,19 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
     ad.q_stride[1] = ad.k_stride[1] = ad.v_stride[1] = dkv;
     ad.q_stride[2] = ad.k_stride[2] = ad.v_stride[2] = st * 3 * inner;
     ad.o_stride[0] = sb * inner; ad.o_stride[1] = dkv; ad.o_stride[2] = st * inner;
-    const int64_t estr[4] = {0, L * L, L, 1};
+    // dense (H, L, L) bias, or the Toeplitz table (H, 2L - 1) viewed as bias[h, i, j] =
+    // table[h, (L - 1) + j - i]: row stride -1, so the kernels read it like any strided bias and
+    // the (H, L, L) tensor never exists (49 KB instead of 25 MB at T5-base, L = 1024)
+    const int64_t estr_dense[4] = {0, L * L, L, 1};
+    const int64_t estr_toep[4] = {0, 2 * L - 1, -1, 1};
+    const int64_t *estr = cfg->bias_toeplitz ? estr_toep : estr_dense;
+    const void *bias0 = (position_bias && cfg->bias_toeplitz)
+                            ? (const void *)((const char *)position_bias + (size_t)(L - 1) * e)
+                            : position_bias;
     // t5.py:543-549  scaled=False (ctor :261-270), edge_scores = position_embeddings
     rc = attn_impl(base + w.ctx, nullptr, nullptr, qkv, qkv + (size_t)inner * e,
                    qkv + (size_t)2 * inner * e, &ad, cfg->dtype, nullptr, nullptr, valid_length,
-                   vl_dtype, position_bias, position_bias ? estr : nullptr, 0.0f, base + w.ffn,
+                   vl_dtype, bias0, bias0 ? estr : nullptr, 0.0f, base + w.ffn,
                    w.total - w.ffn, s);
     if (rc) return rc;
     // t5.py:550-551  hidden = hidden + proj(out)

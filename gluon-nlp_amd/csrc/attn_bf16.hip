@@ -192,7 +192,7 @@ attn_fwd_bf16_d64(FusedAttn a) {
     // multiply; p is then bounded by 2^THR, harmless in bf16 (same relative precision).
     const int64_t kbase_idx = (int64_t)tile * KV_TILE;
     const bool tail = DENSE_MASK || !rows_all_ok || (kbase_idx + KV_TILE > kv_len);
-    if (HAS_BIAS) {  // host guarantees unit stride, Lm % 4 == 0 and 8-byte alignment
+    if (HAS_BIAS) {  // host guarantees unit key stride and Lm % 4 == 0; loads may be unaligned
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -334,10 +334,10 @@ bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv) {
   for (int e = 0; e < 3; ++e)
     if (a.os[e] % 8 != 0) return false;
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 != 0) return false;
-  if (a.bias) {  // vector loads of 4 consecutive keys of the bias row
-    if (a.bs[3] != 1 || a.Lm % 4 != 0 || (uintptr_t)a.bias % 8 != 0) return false;
-    for (int e = 0; e < 3; ++e)
-      if (a.bs[e] % 4 != 0) return false;
+  if (a.bias) {  // vector loads of 4 consecutive keys of the bias row: unit key stride, rows a
+    // multiple of 4 keys long; any row / head / batch stride (the Toeplitz table of the T5 stack
+    // has row stride -1: its 8-byte loads are unaligned, which global memory allows)
+    if (a.bs[3] != 1 || a.Lm % 4 != 0 || (uintptr_t)a.bias % 2 != 0) return false;
   }
   if ((uintptr_t)a.o % 16 != 0) return false;
   return true;

@@ -265,30 +265,32 @@ void launch_bucket_embedding(void *out, const void *weight, const int32_t *rel, 
                                                     units, tb);
 }
 
-// out[h, i, j] = weight[bucket(j - i), h]; thread = one (h, i, j); j fastest => coalesced stores,
-// the (num_buckets, H) table stays in L1/L2.
+// out[h, i, j] = weight[bucket(j - i + rel0), h]; thread = one (h, i, j); j fastest => coalesced
+// stores, the (num_buckets, H) table stays in L1/L2.  (rel0 != 0: the one-row Toeplitz table.)
 template <typename T>
 __global__ void __launch_bounds__(256)
 t5_bias_kernel(T *__restrict__ out, const T *__restrict__ weight, int64_t H, int64_t Lq,
-               int64_t Lm, BucketTable tb) {
+               int64_t Lm, int rel0, BucketTable tb) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= H * Lq * Lm) return;
   const int64_t j = idx % Lm;
   const int64_t r = idx / Lm;
   const int64_t i = r % Lq;
   const int64_t h = r / Lq;
-  out[idx] = weight[(int64_t)bucket_of((int)(j - i), tb) * H + h];
+  out[idx] = weight[(int64_t)bucket_of((int)(j - i) + rel0, tb) * H + h];
 }
 
 void launch_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq,
-                        int64_t Lm, const BucketTable &tb, hipStream_t s) {
+                        int64_t Lm, int rel0, const BucketTable &tb, hipStream_t s) {
   const int64_t total = H * Lq * Lm;
   if (total == 0) return;
   dim3 grid((unsigned)((total + 255) / 256));
   if (dtype == GNLP_BF16)
-    t5_bias_kernel<bf16><<<grid, 256, 0, s>>>((bf16 *)out, (const bf16 *)weight, H, Lq, Lm, tb);
+    t5_bias_kernel<bf16><<<grid, 256, 0, s>>>((bf16 *)out, (const bf16 *)weight, H, Lq, Lm, rel0,
+                                              tb);
   else
-    t5_bias_kernel<float><<<grid, 256, 0, s>>>((float *)out, (const float *)weight, H, Lq, Lm, tb);
+    t5_bias_kernel<float><<<grid, 256, 0, s>>>((float *)out, (const float *)weight, H, Lq, Lm, rel0,
+                                               tb);
 }
 
 }  // namespace gnlp

@@ -63,7 +63,7 @@ void launch_bucket(int32_t *out, const int32_t *rel, int64_t n, const BucketTabl
 void launch_bucket_embedding(void *out, const void *weight, const int32_t *rel, int dtype,
                              int64_t n, int64_t units, const BucketTable &tb, hipStream_t s);
 void launch_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq,
-                        int64_t Lm, const BucketTable &tb, hipStream_t s);
+                        int64_t Lm, int rel0, const BucketTable &tb, hipStream_t s);
 
 // embed.hip (false: shape / alignment not supported by the vector kernel)
 bool launch_embedding(void *out, const void *ids, const void *types, int id_dtype,

@@ -57,7 +57,8 @@ class T5BlockParams(Structure):
 
 class T5Cfg(Structure):
     _fields_ = [('d_model', c_int64), ('d_kv', c_int64), ('d_ff', c_int64), ('heads', c_int64),
-                ('gated', c_int), ('dtype', c_int), ('time_major', c_int), ('ln_eps', c_float)]
+                ('gated', c_int), ('dtype', c_int), ('time_major', c_int), ('ln_eps', c_float),
+                ('bias_toeplitz', c_int)]
 
 
 I64x3 = c_int64 * 3
@@ -98,6 +99,8 @@ PROTOTYPES = {
                                       c_int, c_int, c_int, c_void_p]),
     'gnlp_t5_rel_bias': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int,
                                  c_int, c_int, c_void_p]),
+    'gnlp_t5_rel_bias_table': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int,
+                                       c_int, c_int, c_void_p]),
     'gnlp_sinusoidal_embedding': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                           c_void_p]),
     'gnlp_rel_attn_score': (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int,

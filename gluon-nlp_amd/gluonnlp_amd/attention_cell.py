@@ -377,6 +377,18 @@ class RelAttentionScoreCell(torch.nn.Module):
             self._num_buckets, self._max_distance, T.stream(dev)))
         return out
 
+    def self_attn_bias_table(self, Lq, Lm=None):
+        """The same bias as one row per head, (H, Lq + Lm - 1): bias[h, i, j] =
+        table[h, (Lq - 1) + j - i] (the relative position of gen_rel_position is j - i only)."""
+        Lm = Lq if Lm is None else Lm
+        w = self._rel_pos_embed.weight.data
+        dev = T.require_device(w)
+        out = torch.empty((self._num_heads, Lq + Lm - 1), dtype=w.dtype, device=dev)
+        _lib.check(_lib.load().gnlp_t5_rel_bias_table(
+            T.ptr(out), T.ptr(w), T.code(w), self._num_heads, Lq, Lm, int(self._bidirectional),
+            self._num_buckets, self._max_distance, T.stream(dev)))
+        return out
+
     def forward(self, rel_positions, query=None):
         """rel_positions (Lq, Lm) -> 't5': (num_heads, Lq, Lm); 'transformer_xl' / 'shaw' (need
         ``query`` in the cell's layout): (batch, num_heads, Lq, Lm).  attention_cell.py:796-881."""

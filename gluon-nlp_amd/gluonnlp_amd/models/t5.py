@@ -176,8 +176,10 @@ class T5Block(nn.Module):
         return self.ffn(hidden_states)
 
 
-def run_t5_blocks(blocks, hidden_states, valid_length, position_bias, final_ln, layout):
-    """All blocks (+ the final RMSNorm) in ONE C call (gnlp_t5_encoder_forward)."""
+def run_t5_blocks(blocks, hidden_states, valid_length, position_bias, final_ln, layout,
+                  toeplitz=False):
+    """All blocks (+ the final RMSNorm) in ONE C call (gnlp_t5_encoder_forward).  ``toeplitz``:
+    ``position_bias`` is the (H, 2L - 1) table of RelAttentionScoreCell.self_attn_bias_table."""
     x = T.as_tensor(hidden_states)
     pb = T.as_tensor(position_bias)
     vlt, vlp, vlc = T.valid_length_arg(valid_length)
@@ -194,9 +196,16 @@ def run_t5_blocks(blocks, hidden_states, valid_length, position_bias, final_ln, 
     if pb is not None:
         if pb.dtype != x.dtype:
             pb = pb.to(x.dtype)
-        pb = torch.broadcast_to(pb, (b0._num_heads, L, L)).contiguous()
+        if toeplitz:
+            if tuple(pb.shape) != (b0._num_heads, 2 * L - 1):
+                raise ValueError('bias table {} != (heads, 2L - 1) = {}'.format(
+                    tuple(pb.shape), (b0._num_heads, 2 * L - 1)))
+            pb = pb.contiguous()
+        else:
+            pb = torch.broadcast_to(pb, (b0._num_heads, L, L)).contiguous()
     n = len(blocks)
     cfg = b0.cfg_struct(T.code(x))
+    cfg.bias_toeplitz = int(bool(toeplitz))
     arr = (_lib.T5BlockParams * n)(*[b.params_struct() for b in blocks])
     lib = _lib.load()
     ws = T.workspace(dev, lib.gnlp_t5_workspace_bytes(ctypes.byref(cfg), B, L))
@@ -243,13 +252,15 @@ class T5Encoder(nn.Module):
         return self._layout
 
     def forward(self, hidden_states, valid_length):
-        """models/t5.py:666-711: the (H, L, L) bias is built once (fused rel-position + bucket +
-        gather kernel) and shared by every layer and batch element."""
+        """models/t5.py:666-711.  The reference materialises the (H, L, L) bias and every layer
+        and batch element re-reads it; it depends on j - i only, so the stack is given the
+        (H, 2L - 1) table instead (one fused rel-position + bucket + gather launch) and the
+        attention kernel indexes it with a row stride of -1."""
         x = T.as_tensor(hidden_states)
         L = x.shape[self._time_axis]
-        position_embeddings = self.relative_position_encoder.self_attn_bias(L)
-        return run_t5_blocks(list(self.layers), hidden_states, valid_length, position_embeddings,
-                             self.final_layer_norm, self._layout)
+        table = self.relative_position_encoder.self_attn_bias_table(L)
+        return run_t5_blocks(list(self.layers), hidden_states, valid_length, table,
+                             self.final_layer_norm, self._layout, toeplitz=True)
 
 
 class T5Decoder(nn.Module):

@@ -194,6 +194,13 @@ int gnlp_bucket_embedding(void *out, const void *weight, const int32_t *rel, int
 int gnlp_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq, int64_t Lm,
                      int bidirectional, int num_buckets, int max_distance, gnlp_stream_t stream);
 
+/* The same bias as one row per head: out (H, Lq + Lm - 1), out[h, t] = weight[bucket(t - (Lq-1)), h],
+ * i.e. bias[h, i, j] = out[h, (Lq - 1) + j - i].  gen_rel_position gives j - i only
+ * (attention_cell.py:653-655), so the (H, Lq, Lm) tensor of :876-878 is Toeplitz. */
+int gnlp_t5_rel_bias_table(void *out, const void *weight, int dtype, int64_t H, int64_t Lq,
+                           int64_t Lm, int bidirectional, int num_buckets, int max_distance,
+                           gnlp_stream_t stream);
+
 /* SinusoidalPositionalEmbedding.forward   layers.py:429-450: out (n, units) =
  * concat(sin(p * base_mult), cos(p * base_mult) [, 0 when units is odd]); positions float32 (n),
  * base_mult float32 (units / 2) = exp(arange(units/2) * -log(10000) / (units/2 - 1)) (:418-422). */
@@ -285,11 +292,14 @@ typedef struct {
   int64_t d_model, d_kv, d_ff, heads;
   int gated, dtype, time_major;          /* gated: 0 = relu, 1 = gated-gelu(tanh) */
   float ln_eps;
+  int bias_toeplitz;                     /* position_bias is the (H, 2L-1) table of gnlp_t5_rel_bias_table */
 } gnlp_t5_cfg;
 
 size_t gnlp_t5_workspace_bytes(const gnlp_t5_cfg *cfg, int64_t B, int64_t L);
 
-/* position_bias: (H, L, L) from gnlp_t5_rel_bias.  final_ln_g / final_ln_b: final RMSNorm gamma /
+/* position_bias: (H, L, L) from gnlp_t5_rel_bias, or with cfg->bias_toeplitz the (H, 2L-1) table
+ * from gnlp_t5_rel_bias_table (the bias depends on j - i only; the kernels read the table through
+ * a row stride of -1, so the (H, L, L) tensor is never formed).  final_ln_g / final_ln_b: final RMSNorm gamma /
  * beta (final_ln_g == NULL = run the blocks only; beta may be NULL).  The RMSNorm inside the FFN
  * uses eps 1e-6 whatever cfg->ln_eps says, as the reference does (layers.py:67-68 does not
  * forward epsilon to RMSNorm). */
