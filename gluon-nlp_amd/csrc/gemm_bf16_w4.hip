@@ -1,0 +1,485 @@
+// bf16 MFMA dense layer, PERSISTENT 256x256x64 kernel with ONE wave per SIMD (4 waves, each a
+// 128x128 block of the tile) for gfx950 -- the same GEMMs as gemm_bf16_ps.hip (QKV /
+// attention_proj / FFN-1 / FFN-2 of models/transformer.py:193-206,261,266 and layers.py:590-612).
+//
+// Why a second shape of the same tile: with 8 waves (128x64 each) a K-tile costs 192 KiB of LDS
+// fragment reads and the two waves of a SIMD trade the matrix pipe at barriers; measured 1.75 us
+// per K-tile and CU against 1.0-1.1 us of MFMA time.  With 4 waves of 128x128 the fragment reads
+// drop to 128 KiB, each wave streams its 128 MFMAs per K-tile without handing the pipe over, and
+// the memory instructions (32 ds_read_b128 + 16 LDS-DMA per wave and K-tile) ride in the issue
+// slots between MFMAs.  256 accumulator registers + 128 fragment registers per lane: one wave per
+// SIMD owns the whole 512-entry register file.
+//
+// K-tile g lives in LDS buffer X = g & 1, g + 1 in Y.  Per K-tile (MFMA index t = 0..127, k-step
+// s = t / 64 uses the fragment registers fa[s], fb[s]):
+//   t  1..15   ds_read A fragments of k-step 1 from X          (k-step 0 was read during g - 1)
+//   t  19      lgkmcnt(0), barrier 1: every wave has read all of X's A panel
+//   t  20..50  LDS-DMA A(g+2) -> X (8 pieces of 1 KiB), ds_read B fragments of k-step 1 from X
+//   t  53      lgkmcnt(0), barrier 2: every wave has read all of X's B panel
+//   t  54..82  LDS-DMA B(g+2) -> X (8 pieces)
+//   t  87      vmcnt(16) (all of g + 1 has landed for this wave), barrier 3: Y is complete
+//   t  88..118 ds_read A and B fragments of k-step 0 of g + 1 from Y
+// so a K-tile is requested almost two K-tiles before its first use out of two 64 KiB buffers.
+// The stream of K-tiles runs across the tiles of the workgroup; between the last K-tile of a tile
+// and the first of the next the 256 accumulators are drained (bias, activation, residual, bf16
+// store in full 128-byte lines through a 4 KiB LDS transpose image per wave) while the next
+// tile's first two K-tiles are already in flight.
+//
+// Same arithmetic, in the same order, as gemm_bf16_ps.hip / gemm_bf16_pp.hip: results are
+// bit-identical to theirs.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace gnlp {
+
+struct DenseW4Args {
+  const bf16 *x, *w, *bias, *other;
+  bf16 *out;
+  int64_t ldx, ldo, ldother;
+  int K, nk, combine, tiles_m, tiles_n, group_m;
+};
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <class F, int... I>
+__device__ __forceinline__ void w4_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void w4_static_for(F &&f) {
+  w4_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// piece index issued after MFMA t for a run of n pieces starting at t0, one every `step` MFMAs
+constexpr int w4_slot(int t, int t0, int step, int n) {
+  return (t >= t0 && (t - t0) % step == 0 && (t - t0) / step < n) ? (t - t0) / step : -1;
+}
+// where the 16 LDS-DMA of a K-tile go (developer variants; 0 is the default)
+template <int SCHED> struct W4Sched;
+template <> struct W4Sched<0> { static constexpr int a0 = 20, as = 4, b0 = 54, bs = 4, vm = 16; };
+template <> struct W4Sched<1> { static constexpr int a0 = 20, as = 8, b0 = 56, bs = 8, vm = 12; };
+template <> struct W4Sched<2> { static constexpr int a0 = 20, as = 2, b0 = 54, bs = 2, vm = 16; };
+// 3: no LDS-DMA -- buffer_load into 64 staging VGPRs early in the K-tile, ds_write_b128 late
+template <> struct W4Sched<3> { static constexpr int a0 = -1, as = 1, b0 = -1, bs = 1, vm = 0; };
+
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+#define W4_BAR()                       \
+  do {                                 \
+    W4_SB();                           \
+    __builtin_amdgcn_s_barrier();      \
+    W4_SB();                           \
+  } while (0)
+#define W4_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int ACT, bool HAS_OTHER, int ABL = 0, int SCHED = 0>
+__global__ void __launch_bounds__(256)
+dense_bf16_w4_kernel(DenseW4Args a) {
+#if __HIP_DEVICE_COMPILE__   // (the buffer-resource builtins exist in the device pass only)
+  typedef W4Sched<SCHED> SC;
+  constexpr int HALF = 128 * 128;        // bytes of one half-panel (128 rows x 64 bf16)
+  constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1 of one K-tile
+  constexpr int SCRATCH = 2 * BUF;       // 4 x 4 KiB transpose images
+  constexpr int BIAS = SCRATCH + 16384;  // the whole bias vector (N <= 8192)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- the tiles of this workgroup (same walk as gemm_bf16_ps.hip) ----
+  const int nt = a.tiles_m * a.tiles_n;
+  const int S = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q8 = nt >> 3, r8 = nt & 7;
+  const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+  const int n_my = slot < xcnt ? (xcnt - slot + S - 1) / S : 0;
+  if (n_my == 0) return;   // uniform over the workgroup
+  auto coords = [&](int i, int &m0, int &n0) {
+    const int tile = xbase + slot + i * S;
+    const int GROUP_M = a.group_m;
+    const int band = tile / (GROUP_M * a.tiles_n);
+    const int band_m0 = band * GROUP_M;
+    const int band_h = (a.tiles_m - band_m0) < GROUP_M ? (a.tiles_m - band_m0) : GROUP_M;
+    const int in_band = tile - band * GROUP_M * a.tiles_n;
+    m0 = (band_m0 + in_band % band_h) * 256;
+    n0 = (in_band / band_h) * 256;
+  };
+
+  // ---- staging: wave w moves pieces w, w+4, w+8, w+12 (8 rows x 128 B each) of every half-panel,
+  // so that the source-side XOR swizzle of a lane is the same for all of its pieces ----
+  const int srow = lane >> 3, cpos = lane & 7;
+  unsigned offA, offB;   // per-lane byte offsets inside a panel, tile- and piece-invariant
+  {
+    const int row = wave * 8 + srow;
+    const int c = cpos ^ ((row >> 1) & 7);
+    offA = (unsigned)(row * (int)a.ldx + c * 8) * 2u;
+    offB = (unsigned)(row * a.K + c * 8) * 2u;
+  }
+  // The loads are buffer_load ... lds: one resource descriptor per operand (base = the K-tile's
+  // first element), the lane's offset in a VGPR that never changes, the piece's offset in an SGPR
+  // that never changes -- no vector-ALU instruction per piece (a VALU instruction between MFMAs
+  // stalls the matrix pipe on gfx950; with global_load_lds and 64-bit lane addresses the 16 pieces
+  // of a K-tile cost 0.5 us of the 2.0).
+  int soffA[8], soffB[8];   // byte offsets of the pieces inside a K-tile panel (uniform)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    soffA[p] = (int)(((p >> 2) * 128 + (p & 3) * 32) * a.ldx * 2);
+    soffB[p] = (int)(((p >> 2) * 128 + (p & 3) * 32) * (int64_t)a.K * 2);
+  }
+  auto rsrc = [](const bf16 *base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
+  };
+  auto stage_a = [&](char *buf, const bf16 *base, int p) {   // p = 0..7: half p>>2, quarter p&3
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsrc(base), (lptr_t)(buf + (p >> 2) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offA,
+        soffA[p], 0, 0);
+  };
+  auto stage_b = [&](char *buf, const bf16 *base, int p) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsrc(base), (lptr_t)(buf + (2 + (p >> 2)) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offB,
+        soffB[p], 0, 0);
+  };
+
+  // register staging (SCHED 3)
+  constexpr bool VST = SCHED == 3;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 stA[8], stB[8];
+  const int wr_off = wave * 1024 + lane * 16;
+  auto ld_a = [&](const bf16 *base, int p) {
+    stA[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base), offA, soffA[p], 0);
+  };
+  auto ld_b = [&](const bf16 *base, int p) {
+    stB[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base), offB, soffB[p], 0);
+  };
+  auto wr_a = [&](char *buf, int p) {
+    *reinterpret_cast<u32x4 *>(buf + (p >> 2) * HALF + (p & 3) * 4096 + wr_off) = stA[p];
+  };
+  auto wr_b = [&](char *buf, int p) {
+    *reinterpret_cast<u32x4 *>(buf + (2 + (p >> 2)) * HALF + (p & 3) * 4096 + wr_off) = stB[p];
+  };
+
+  // ---- fragment reads ----
+  const int fr = lane & 15, fq = lane >> 4;
+  const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+  const int a_off = wm * HALF + frag_off;
+  const int b_off = (2 + wn) * HALF + frag_off;
+
+  f32x4 acc[8][8];   // [n-frag][m-frag]
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][8], fb[2][8];   // [k-step][frag]
+
+  auto rd_a = [&](const char *buf, int s, int i) {
+    fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + ((a_off + i * 2048) ^ (s << 6)));
+  };
+  auto rd_b = [&](const char *buf, int s, int j) {
+    fb[s][j] = *reinterpret_cast<const bf16x8 *>(buf + ((b_off + j * 2048) ^ (s << 6)));
+  };
+
+  // ---- one K-tile: 128 MFMAs with the memory instructions in between (see the header) ----
+  auto ktile = [&](char *X, char *Y, const bf16 *pA, const bf16 *pB) {
+    w4_static_for<128>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int s = t >> 6, j = (t >> 3) & 7, i = t & 7;
+      // (inline asm: the accumulators are pinned to the AGPR half of the register file; left to
+      // the register allocator they wander between the halves, hundreds of copies per K-tile)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                   : "+a"(acc[j][i])
+                   : "v"(fb[s][j]), "v"(fa[s][i]));
+      constexpr bool DMA = !(ABL & 1), BARS = !(ABL & 2), RD = !(ABL & 4);   // timing-only
+      if constexpr (RD && t < 16 && (t & 1)) rd_a(X, 1, t >> 1);
+      if constexpr (t == 19) {
+        W4_SB();
+        W4_LGKM0();
+        if constexpr (BARS) W4_BAR();
+      }
+      constexpr int pa = w4_slot(t, SC::a0, SC::as, 8), pb = w4_slot(t, SC::b0, SC::bs, 8);
+      if constexpr (DMA && !VST && pa >= 0) stage_a(X, pA, pa);
+      if constexpr (VST) {
+        constexpr int la = w4_slot(t, 4, 4, 8), lb = w4_slot(t, 36, 4, 8);
+        constexpr int wa = w4_slot(t, 66, 4, 8), wb = w4_slot(t, 96, 4, 8);
+        if constexpr (la >= 0) ld_a(pA, la);
+        if constexpr (lb >= 0) ld_b(pB, lb);
+        if constexpr (wa >= 0) wr_a(X, wa);
+        if constexpr (wb >= 0) wr_b(X, wb);
+      }
+      if constexpr (RD && t >= 22 && t <= 50 && ((t - 22) & 3) == 0) rd_b(X, 1, (t - 22) >> 2);
+      if constexpr (t == 53) {
+        W4_SB();
+        W4_LGKM0();
+        if constexpr (BARS) W4_BAR();
+      }
+      if constexpr (DMA && !VST && pb >= 0) stage_b(X, pB, pb);
+      if constexpr (t == 87 && !VST) {
+        W4_SB();
+        if constexpr (DMA) {
+          if constexpr (SC::vm == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        }
+        if constexpr (BARS) W4_BAR();
+      }
+      if constexpr (RD && t >= 88 && t <= 102 && !(t & 1)) rd_a(Y, 0, (t - 88) >> 1);
+      if constexpr (RD && t >= 104 && t <= 118 && !(t & 1)) rd_b(Y, 0, (t - 104) >> 1);
+      W4_SB();
+    });
+  };
+
+  // ---- drain of the whole 128x128 block of this wave ----
+  char *scr = smem + SCRATCH + wave * 4096;
+  auto drain = [&](int m0, int n0) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int c8 = ln & 7, rr8 = ln >> 3, dfr = ln & 15, dfq = ln >> 4;
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn) {   // 64-column halves of the wave's 128 columns
+      const int64_t n = n0 + wn * 128 + hn * 64 + c8 * 8;
+      const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(smem + BIAS + n * 2);
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {   // two 16-row slabs per LDS round trip
+        const int64_t mrow = m0 + wm * 128 + sp * 32 + rr8;
+        bf16x8 o8[2][2];
+        if (HAS_OTHER) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+              o8[q][it] = *reinterpret_cast<const bf16x8 *>(
+                  a.other + (mrow + q * 16 + it * 8) * a.ldother + n);
+        }
+        f32x4 lo[2][2], hi[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int s = 2 * sp + q;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x4 *>(scr + dfr * 256 + (((j * 4 + dfq) ^ dfr) << 4)) =
+                acc[hn * 4 + j][s];
+            acc[hn * 4 + j][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + rr8;
+            const char *rp = scr + row * 256;
+            lo[q][it] = *reinterpret_cast<const f32x4 *>(rp + (((2 * c8) ^ row) << 4));
+            hi[q][it] = *reinterpret_cast<const f32x4 *>(rp + (((2 * c8 + 1) ^ row) << 4));
+          }
+          W4_SB();   // keep write -> read -> write -> read as written (LDS serves a wave in order)
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            float v[8];
+            if (ACT == GNLP_ACT_GELU_ERF) {
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                const f32x2 g0 =
+                    gelu_erf_fast2((f32x2){lo[q][it][e] + bv[e], lo[q][it][e + 1] + bv[e + 1]});
+                const f32x2 g1 = gelu_erf_fast2(
+                    (f32x2){hi[q][it][e] + bv[4 + e], hi[q][it][e + 1] + bv[5 + e]});
+                v[e] = g0[0]; v[e + 1] = g0[1]; v[4 + e] = g1[0]; v[5 + e] = g1[1];
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] = apply_act<false>(lo[q][it][e] + bv[e], ACT);
+                v[4 + e] = apply_act<false>(hi[q][it][e] + bv[4 + e], ACT);
+              }
+            }
+            if (HAS_OTHER) {
+              if (a.combine == GNLP_COMBINE_MUL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= (float)o8[q][it][e];
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)o8[q][it][e];
+              }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x8 *>(a.out + (mrow + q * 16 + it * 8) * a.ldo + n) = o;
+          }
+      }
+    }
+  };
+
+  // ---- producer cursor: the next K-tile to request, running ahead of the MFMAs by two ----
+  const int nk = a.nk;
+  int p_tile = 0, p_kt = 0;
+  int pm0, pn0;
+  coords(0, pm0, pn0);
+  const bf16 *pA = a.x + (int64_t)pm0 * a.ldx, *pB = a.w + (int64_t)pn0 * a.K;
+  const bf16 *const dA = pA, *const dB = pB;   // a valid source for the two requests past the end
+  auto advance = [&]() {
+    if (++p_kt < nk) {
+      pA += 64; pB += 64;
+    } else {
+      p_kt = 0;
+      if (++p_tile < n_my) {
+        coords(p_tile, pm0, pn0);
+        pA = a.x + (int64_t)pm0 * a.ldx;
+        pB = a.w + (int64_t)pn0 * a.K;
+      } else {
+        p_tile = n_my;   // stay past the end
+        p_kt = nk;       // (re-enters this branch)
+        pA = dA; pB = dB;
+      }
+    }
+  };
+
+  // ---- the bias vector goes to LDS once (zeros without a bias) ----
+  const bool has_bias = a.bias != nullptr;
+  for (int i = threadIdx.x * 8; i < a.tiles_n * 256; i += 256 * 8) {
+    bf16x8 b8;
+    if (has_bias) {
+      b8 = *reinterpret_cast<const bf16x8 *>(a.bias + i);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b8[e] = (bf16)0.f;
+    }
+    *reinterpret_cast<bf16x8 *>(smem + BIAS + i * 2) = b8;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1, fragments of k-step 0 ----
+  if constexpr (VST) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) ld_a(pA, p);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) ld_b(pB, p);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) wr_a(smem + g * BUF, p);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) wr_b(smem + g * BUF, p);
+      advance();
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_a(smem, pA, p);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_b(smem, pB, p);
+    advance();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_a(smem + BUF, pA, p);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_b(smem + BUF, pB, p);
+    advance();
+  }
+  W4_SB();
+  if constexpr (!VST) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  W4_LGKM0();   // the bias image
+  W4_BAR();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rd_a(smem, 0, i);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rd_b(smem, 0, j);
+
+  int par = 0;
+  for (int ti = 0; ti < n_my; ++ti) {
+    int m0, n0;
+    coords(ti, m0, n0);
+    for (int t = 0; t < nk; ++t) {
+      ktile(smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
+      advance();
+      par ^= 1;
+    }
+    drain(m0, n0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two requests past the end
+#endif
+}
+
+bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                                  int64_t ldother, const void *out, const void *bias,
+                                  const void *other) {
+  // the same contract as the 8-wave persistent kernel
+  return mfma_bf16_dense_ps_supported(M, N, K, ldx, ldo, ldother, out, bias, other);
+}
+
+static int w4_cu_count() {   // of the current device
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = cache[dev & 63].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t p;
+    n = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 0;
+    if (n < 8) n = 256;
+    cache[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+template <int ACT, bool HAS_OTHER, int ABL = 0, int SCHED = 0>
+static void launch_w4_act(const DenseW4Args &a, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 128 + 4 * 4096 + 16384;   // 160 KiB
+  static PerDeviceFlag attr;
+  attr.once([&] {
+    (void)hipFuncSetAttribute((const void *)dense_bf16_w4_kernel<ACT, HAS_OTHER, ABL, SCHED>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  const int nt = a.tiles_m * a.tiles_n;
+  int grid = w4_cu_count() & ~7;         // one workgroup per CU, a multiple of the 8 XCDs
+  const int need = ((nt + 7) / 8) * 8;   // fewer tiles than CUs: one tile each
+  if (grid > need) grid = need;
+  dense_bf16_w4_kernel<ACT, HAS_OTHER, ABL, SCHED><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
+}
+
+template <int ACT>
+static void launch_w4_other(const DenseW4Args &a, hipStream_t s) {
+  if (a.other) launch_w4_act<ACT, true>(a, s);
+  else launch_w4_act<ACT, false>(a, s);
+}
+
+void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const void *bias,
+                               const void *other, int combine, int act, int64_t M, int64_t N,
+                               int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
+                               hipStream_t s) {
+  DenseW4Args a;
+  a.x = (const bf16 *)x; a.w = (const bf16 *)w; a.bias = (const bf16 *)bias;
+  a.other = (const bf16 *)other; a.out = (bf16 *)out;
+  a.ldx = ldx; a.ldo = ldo; a.ldother = ldother;
+  a.K = (int)K; a.nk = (int)(K >> 6); a.combine = combine;
+  a.tiles_m = (int)(M / 256);
+  a.tiles_n = (int)(N / 256);
+  const char *gm = getenv("GNLP_GROUP_M");   // developer knob
+  a.group_m = gm ? atoi(gm) : 8;
+  if (a.group_m < 1) a.group_m = 1;
+  const char *abl = getenv("GNLP_W4_ABL");   // TIMING-ONLY ablations (wrong results)
+  if (abl && a.other && act == GNLP_ACT_IDENTITY) {
+    switch (atoi(abl)) {
+      case 1: launch_w4_act<GNLP_ACT_IDENTITY, true, 1>(a, s); return;
+      case 2: launch_w4_act<GNLP_ACT_IDENTITY, true, 2>(a, s); return;
+      case 3: launch_w4_act<GNLP_ACT_IDENTITY, true, 3>(a, s); return;
+      case 4: launch_w4_act<GNLP_ACT_IDENTITY, true, 4>(a, s); return;
+      case 5: launch_w4_act<GNLP_ACT_IDENTITY, true, 5>(a, s); return;
+      case 7: launch_w4_act<GNLP_ACT_IDENTITY, true, 7>(a, s); return;
+      case 10: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 1>(a, s); return;
+      case 20: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 2>(a, s); return;
+      case 30: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 3>(a, s); return;
+      default: break;
+    }
+  }
+  switch (act) {
+    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, s); break;
+    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, s); break;
+    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, s); break;
+    default: launch_w4_other<GNLP_ACT_IDENTITY>(a, s); break;
+  }
+}
+
+}  // namespace gnlp

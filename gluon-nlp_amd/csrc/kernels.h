@@ -117,6 +117,14 @@ void launch_mfma_bf16_dense_ps(void *out, const void *x, const void *w, const vo
                                const void *other, int combine, int act, int64_t M, int64_t N,
                                int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
                                hipStream_t s);
+// One-wave-per-SIMD form (gemm_bf16_w4.hip): 4 waves of 128x128, same contract as the _ps kernel.
+bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                                  int64_t ldother, const void *out, const void *bias,
+                                  const void *other);
+void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const void *bias,
+                               const void *other, int combine, int act, int64_t M, int64_t N,
+                               int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
+                               hipStream_t s);
 bool mfma_bf16_dense_pp_supported(int64_t N, int64_t ldo, int64_t ldother, const void *out,
                                   const void *bias, const void *other);
 void launch_mfma_bf16_dense_pp(void *out, const void *x, const void *w, const void *bias,
