@@ -68,6 +68,11 @@ template <> struct W4Sched<1> { static constexpr int a0 = 20, as = 8, b0 = 56, b
 template <> struct W4Sched<2> { static constexpr int a0 = 20, as = 2, b0 = 54, bs = 2, vm = 16; };
 // 3: no LDS-DMA -- buffer_load into 64 staging VGPRs early in the K-tile, ds_write_b128 late
 template <> struct W4Sched<3> { static constexpr int a0 = -1, as = 1, b0 = -1, bs = 1, vm = 0; };
+// 4: as 3, with the XOR swizzle on the ds_write side (linear global addresses per row)
+template <> struct W4Sched<4> { static constexpr int a0 = -1, as = 1, b0 = -1, bs = 1, vm = 0; };
+// 5: as 0, wave w issues each piece w MFMAs later: the four waves reach a barrier together and
+// would otherwise all present their LDS-DMA to the CU's one address unit in the same cycles
+template <> struct W4Sched<5> { static constexpr int a0 = 20, as = 4, b0 = 54, bs = 4, vm = 16; };
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 #define W4_BAR()                       \
@@ -118,7 +123,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   unsigned offA, offB;   // per-lane byte offsets inside a panel, tile- and piece-invariant
   {
     const int row = wave * 8 + srow;
-    const int c = cpos ^ ((row >> 1) & 7);
+    // ABL 8: linear source (timing only); SCHED 4: linear source, swizzle applied by the ds_write
+    const int c = ((ABL & 8) || SCHED == 4) ? cpos : cpos ^ ((row >> 1) & 7);
     offA = (unsigned)(row * (int)a.ldx + c * 8) * 2u;
     offB = (unsigned)(row * a.K + c * 8) * 2u;
   }
@@ -148,10 +154,12 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   };
 
   // register staging (SCHED 3)
-  constexpr bool VST = SCHED == 3;
+  constexpr bool VST = SCHED == 3 || SCHED == 4;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   u32x4 stA[8], stB[8];
-  const int wr_off = wave * 1024 + lane * 16;
+  const int wr_off =
+      SCHED == 4 ? wave * 1024 + srow * 128 + ((cpos ^ (((wave * 8 + srow) >> 1) & 7)) << 4)
+                 : wave * 1024 + lane * 16;
   auto ld_a = [&](const bf16 *base, int p) {
     stA[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base), offA, soffA[p], 0);
   };
@@ -171,11 +179,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   const int a_off = wm * HALF + frag_off;
   const int b_off = (2 + wn) * HALF + frag_off;
 
-  f32x4 acc[8][8];   // [n-frag][m-frag]
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[8][8];   // [n-frag][m-frag]; first written by the tile's first K-tile
   bf16x8 fa[2][8], fb[2][8];   // [k-step][frag]
 
   auto rd_a = [&](const char *buf, int s, int i) {
@@ -186,15 +190,25 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   };
 
   // ---- one K-tile: 128 MFMAs with the memory instructions in between (see the header) ----
-  auto ktile = [&](char *X, char *Y, const bf16 *pA, const bf16 *pB) {
+  // FIRST: the tile's first K-tile starts the accumulators from the inline constant 0 (no
+  // zeroing pass over 256 registers per tile).
+  auto ktile = [&](auto firstc, auto wc, char *X, char *Y, const bf16 *pA,
+                   const bf16 *pB) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(firstc)::value;
+    constexpr int WSKEW = SCHED == 5 ? decltype(wc)::value : 0;
     w4_static_for<128>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
       constexpr int s = t >> 6, j = (t >> 3) & 7, i = t & 7;
       // (inline asm: the accumulators are pinned to the AGPR half of the register file; left to
       // the register allocator they wander between the halves, hundreds of copies per K-tile)
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
-                   : "+a"(acc[j][i])
-                   : "v"(fb[s][j]), "v"(fa[s][i]));
+      if constexpr (FIRST && s == 0)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0"
+                     : "=a"(acc[j][i])
+                     : "v"(fb[s][j]), "v"(fa[s][i]));
+      else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                     : "+a"(acc[j][i])
+                     : "v"(fb[s][j]), "v"(fa[s][i]));
       constexpr bool DMA = !(ABL & 1), BARS = !(ABL & 2), RD = !(ABL & 4);   // timing-only
       if constexpr (RD && t < 16 && (t & 1)) rd_a(X, 1, t >> 1);
       if constexpr (t == 19) {
@@ -202,7 +216,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
         W4_LGKM0();
         if constexpr (BARS) W4_BAR();
       }
-      constexpr int pa = w4_slot(t, SC::a0, SC::as, 8), pb = w4_slot(t, SC::b0, SC::bs, 8);
+      constexpr int pa = w4_slot(t - WSKEW, SC::a0, SC::as, 8);
+      constexpr int pb = w4_slot(t - WSKEW, SC::b0, SC::bs, 8);
       if constexpr (DMA && !VST && pa >= 0) stage_a(X, pA, pa);
       if constexpr (VST) {
         constexpr int la = w4_slot(t, 4, 4, 8), lb = w4_slot(t, 36, 4, 8);
@@ -235,7 +250,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 
   // ---- drain of the whole 128x128 block of this wave ----
   char *scr = smem + SCRATCH + wave * 4096;
-  auto drain = [&](int m0, int n0) {
+  auto drain = [&](int m0, int n0) __attribute__((always_inline)) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int c8 = ln & 7, rr8 = ln >> 3, dfr = ln & 15, dfq = ln >> 4;
@@ -266,7 +281,6 @@ dense_bf16_w4_kernel(DenseW4Args a) {
           for (int j = 0; j < 4; ++j) {
             *reinterpret_cast<f32x4 *>(scr + dfr * 256 + (((j * 4 + dfq) ^ dfr) << 4)) =
                 acc[hn * 4 + j][s];
-            acc[hn * 4 + j][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
@@ -388,16 +402,29 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) rd_b(smem, 0, j);
 
-  int par = 0;
-  for (int ti = 0; ti < n_my; ++ti) {
-    int m0, n0;
-    coords(ti, m0, n0);
-    for (int t = 0; t < nk; ++t) {
-      ktile(smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
+  auto stream = [&](auto wc) __attribute__((always_inline)) {
+    int par = 0;
+    for (int ti = 0; ti < n_my; ++ti) {
+      int m0, n0;
+      coords(ti, m0, n0);
+      ktile(std::true_type{}, wc, smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
       advance();
       par ^= 1;
+      for (int t = 1; t < nk; ++t) {
+        ktile(std::false_type{}, wc, smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
+        advance();
+        par ^= 1;
+      }
+      drain(m0, n0);
     }
-    drain(m0, n0);
+  };
+  if constexpr (SCHED == 5) {   // one copy of the stream per wave: the skew is a compile-time slot
+    if (wave == 0) stream(std::integral_constant<int, 0>{});
+    else if (wave == 1) stream(std::integral_constant<int, 1>{});
+    else if (wave == 2) stream(std::integral_constant<int, 2>{});
+    else stream(std::integral_constant<int, 3>{});
+  } else {
+    stream(std::integral_constant<int, 0>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two requests past the end
 #endif
@@ -468,9 +495,12 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
       case 4: launch_w4_act<GNLP_ACT_IDENTITY, true, 4>(a, s); return;
       case 5: launch_w4_act<GNLP_ACT_IDENTITY, true, 5>(a, s); return;
       case 7: launch_w4_act<GNLP_ACT_IDENTITY, true, 7>(a, s); return;
+      case 12: launch_w4_act<GNLP_ACT_IDENTITY, true, 12>(a, s); return;
       case 10: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 1>(a, s); return;
       case 20: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 2>(a, s); return;
       case 30: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 3>(a, s); return;
+      case 40: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 4>(a, s); return;
+      case 50: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 5>(a, s); return;
       default: break;
     }
   }
