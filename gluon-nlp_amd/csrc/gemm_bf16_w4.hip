@@ -73,6 +73,10 @@ template <> struct W4Sched<4> { static constexpr int a0 = -1, as = 1, b0 = -1, b
 // 5: as 0, wave w issues each piece w MFMAs later: the four waves reach a barrier together and
 // would otherwise all present their LDS-DMA to the CU's one address unit in the same cycles
 template <> struct W4Sched<5> { static constexpr int a0 = 20, as = 4, b0 = 54, bs = 4, vm = 16; };
+// 6: as 0 with the LINEAR LDS image: every 8-lane group of an LDS-DMA reads one 128-byte row in
+// address order (no XOR on the source side); bank conflicts are avoided by which rows share a
+// 1 KiB piece and by 32 bytes of padding per piece instead (see "LIN" in the kernel)
+template <> struct W4Sched<6> { static constexpr int a0 = 20, as = 4, b0 = 54, bs = 4, vm = 16; };
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 #define W4_BAR()                       \
@@ -88,7 +92,14 @@ __global__ void __launch_bounds__(256)
 dense_bf16_w4_kernel(DenseW4Args a) {
 #if __HIP_DEVICE_COMPILE__   // (the buffer-resource builtins exist in the device pass only)
   typedef W4Sched<SCHED> SC;
-  constexpr int HALF = 128 * 128;        // bytes of one half-panel (128 rows x 64 bf16)
+  // LIN: a half-panel is 4 groups of 4 pieces; piece (w, k) = 8 rows at k * 4224 + w * 1056 bytes
+  // (32 bytes of padding per piece, 4224 = 4 * 1056).  Tile row 32 k + r5 (r5 = 0..31) lives in
+  // piece (w = r5 & 3, k), slot t = (r5 >> 3 & 1) + 2 (r5 >> 2 & 1) + 4 (r5 >> 4): the 16 rows of
+  // an MFMA fragment then fall on 16-byte bank groups 2 (fr & 3) + 8 (fr >> 3) + chunk, which is
+  // conflict-free for every 16-lane service group of ds_read_b128, with plain chunk order.
+  constexpr bool LIN = SCHED == 6;
+  constexpr int GRP = 4224;
+  constexpr int HALF = LIN ? 4 * GRP : 128 * 128;   // bytes of one half-panel (128 rows x 64 bf16)
   constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1 of one K-tile
   constexpr int SCRATCH = 2 * BUF;       // 4 x 4 KiB transpose images
   constexpr int BIAS = SCRATCH + 16384;  // the whole bias vector (N <= 8192)
@@ -122,9 +133,10 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   const int srow = lane >> 3, cpos = lane & 7;
   unsigned offA, offB;   // per-lane byte offsets inside a panel, tile- and piece-invariant
   {
-    const int row = wave * 8 + srow;
+    const int row = LIN ? 16 * (srow >> 2) + wave + 4 * ((srow >> 1) & 1) + 8 * (srow & 1)
+                        : wave * 8 + srow;
     // ABL 8: linear source (timing only); SCHED 4: linear source, swizzle applied by the ds_write
-    const int c = ((ABL & 8) || SCHED == 4) ? cpos : cpos ^ ((row >> 1) & 7);
+    const int c = ((ABL & 8) || SCHED == 4 || LIN) ? cpos : cpos ^ ((row >> 1) & 7);
     offA = (unsigned)(row * (int)a.ldx + c * 8) * 2u;
     offB = (unsigned)(row * a.K + c * 8) * 2u;
   }
@@ -144,13 +156,17 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   };
   auto stage_a = [&](char *buf, const bf16 *base, int p) {   // p = 0..7: half p>>2, quarter p&3
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsrc(base), (lptr_t)(buf + (p >> 2) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offA,
-        soffA[p], 0, 0);
+        rsrc(base),
+        (lptr_t)(buf + (p >> 2) * HALF +
+                 (LIN ? (p & 3) * GRP + wave * 1056 : (wave + 4 * (p & 3)) * 1024)),
+        16, offA, soffA[p], 0, 0);
   };
   auto stage_b = [&](char *buf, const bf16 *base, int p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsrc(base), (lptr_t)(buf + (2 + (p >> 2)) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offB,
-        soffB[p], 0, 0);
+        rsrc(base),
+        (lptr_t)(buf + (2 + (p >> 2)) * HALF +
+                 (LIN ? (p & 3) * GRP + wave * 1056 : (wave + 4 * (p & 3)) * 1024)),
+        16, offB, soffB[p], 0, 0);
   };
 
   // register staging (SCHED 3)
@@ -175,7 +191,9 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 
   // ---- fragment reads ----
   const int fr = lane & 15, fq = lane >> 4;
-  const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+  const int frag_off =
+      LIN ? (fr & 3) * 1056 + ((fr >> 3) + 2 * ((fr >> 2) & 1)) * 128 + fq * 16
+          : fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   const int a_off = wm * HALF + frag_off;
   const int b_off = (2 + wn) * HALF + frag_off;
 
@@ -183,10 +201,18 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   bf16x8 fa[2][8], fb[2][8];   // [k-step][frag]
 
   auto rd_a = [&](const char *buf, int s, int i) {
-    fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + ((a_off + i * 2048) ^ (s << 6)));
+    if constexpr (LIN)
+      fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + a_off + (i >> 1) * GRP + (i & 1) * 512 +
+                                                   s * 64);
+    else
+      fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + ((a_off + i * 2048) ^ (s << 6)));
   };
   auto rd_b = [&](const char *buf, int s, int j) {
-    fb[s][j] = *reinterpret_cast<const bf16x8 *>(buf + ((b_off + j * 2048) ^ (s << 6)));
+    if constexpr (LIN)
+      fb[s][j] = *reinterpret_cast<const bf16x8 *>(buf + b_off + (j >> 1) * GRP + (j & 1) * 512 +
+                                                   s * 64);
+    else
+      fb[s][j] = *reinterpret_cast<const bf16x8 *>(buf + ((b_off + j * 2048) ^ (s << 6)));
   };
 
   // ---- one K-tile: 128 MFMAs with the memory instructions in between (see the header) ----
@@ -466,10 +492,20 @@ static void launch_w4_act(const DenseW4Args &a, hipStream_t s) {
   dense_bf16_w4_kernel<ACT, HAS_OTHER, ABL, SCHED><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
 }
 
-template <int ACT>
+template <int ACT, int SCHED>
 static void launch_w4_other(const DenseW4Args &a, hipStream_t s) {
-  if (a.other) launch_w4_act<ACT, true>(a, s);
-  else launch_w4_act<ACT, false>(a, s);
+  if (a.other) launch_w4_act<ACT, true, 0, SCHED>(a, s);
+  else launch_w4_act<ACT, false, 0, SCHED>(a, s);
+}
+
+template <int SCHED>
+static void launch_w4_sched(const DenseW4Args &a, int act, hipStream_t s) {
+  switch (act) {
+    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU, SCHED>(a, s); break;
+    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF, SCHED>(a, s); break;
+    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH, SCHED>(a, s); break;
+    default: launch_w4_other<GNLP_ACT_IDENTITY, SCHED>(a, s); break;
+  }
 }
 
 void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const void *bias,
@@ -501,15 +537,15 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
       case 30: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 3>(a, s); return;
       case 40: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 4>(a, s); return;
       case 50: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 5>(a, s); return;
+      case 60: if (a.tiles_n * 256 <= 6144) { launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 6>(a, s); return; } break;
       default: break;
     }
   }
-  switch (act) {
-    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, s); break;
-    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, s); break;
-    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, s); break;
-    default: launch_w4_other<GNLP_ACT_IDENTITY>(a, s); break;
-  }
+  const char *sc = getenv("GNLP_W4_SCHED");   // developer knob: LDS-DMA placement / LDS image
+  const int sched = sc ? atoi(sc) : 0;
+  if (sched == 1) launch_w4_sched<1>(a, act, s);
+  else if (sched == 6 && a.tiles_n * 256 <= 6144) launch_w4_sched<6>(a, act, s);
+  else launch_w4_sched<0>(a, act, s);
 }
 
 }  // namespace gnlp

@@ -273,8 +273,9 @@ def test_dense(nlp, dtype, M, N, K):
     (2048, 8448, 128),    # N > 8192: one-tile-per-workgroup kernel
 ])
 def test_dense_persistent(nlp, M, N, K, monkeypatch):
-    """The persistent big-GEMM kernel (csrc/gemm_bf16_ps.hip) against the oracle, and bit for bit
-    against the one-tile-per-workgroup kernel (same accumulation order, same fp32 epilogue)."""
+    """The persistent big-GEMM kernels (csrc/gemm_bf16_w4.hip, csrc/gemm_bf16_ps.hip) against the
+    oracle, and bit for bit against each other and the one-tile-per-workgroup kernel (same
+    accumulation order, same fp32 epilogue)."""
     from gluonnlp_amd.layers import Dense
     dtype = torch.bfloat16
     rng = np.random.default_rng(M + N + K)
@@ -306,6 +307,13 @@ def test_dense_persistent(nlp, M, N, K, monkeypatch):
     monkeypatch.delenv('GNLP_GEMM_PS')
     for g, h in zip(got, variants()):
         assert torch.equal(g, h)
+    # the three 256x256x64 kernels (one wave per SIMD, gemm_bf16_w4.hip, the default; 8 waves
+    # persistent, gemm_bf16_ps.hip; one tile per workgroup, gemm_bf16_pp.hip) accumulate in the
+    # same order with the same fp32 epilogue: bit for bit equal
+    monkeypatch.setenv('GNLP_GEMM_W4', '0')
+    for g, h in zip(got, variants()):
+        assert torch.equal(g, h)
+    monkeypatch.delenv('GNLP_GEMM_W4')
 
 
 def test_dense_mfma_layout_asymmetric(nlp):
