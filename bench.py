@@ -236,7 +236,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_pmc.json')))
             for k, v in tj.items():
-                if 'dense_bf16_p' in k and '<2' in k and args.config == 'bert_large' and act == 'gelu':
+                if 'dense_bf16_w4' in k and '<2' in k and args.config == 'bert_large' and act == 'gelu':
                     traffic = (v['fetch_MB_corrected_x2'] + v['write_MB']) * 1048576.0
         except Exception:
             traffic = None
@@ -258,8 +258,10 @@ def main():
             'reference_harness_protocol_ms': harness_ms, 'median_of_20_ms': median_ms,
             'path_tflops': seqs * fps / 1e12,
             'path_frac_of_mfma_peak': seqs * fps / 1e12 / (peak * world),
-            'roofline': {'bound': 'mfma', 'kernel': 'dense_{}_kernel (FFN-1 GEMM + bias + {}), '
-                                                    'M={} N={} K={}'.format(args.dtype, act, M, F, U),
+            'roofline': {'bound': 'mfma',
+                         'kernel': '{} (FFN-1 GEMM + bias + {}), M={} N={} K={}'.format(
+                             'dense_bf16_w4_kernel' if args.dtype == 'bf16' else 'dense_f32_kernel',
+                             act, M, F, U),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
                          'avg_launch_ms': ms, 'launches_measured': n_meas,

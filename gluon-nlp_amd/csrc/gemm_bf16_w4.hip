@@ -2,13 +2,20 @@
 // 128x128 block of the tile) for gfx950 -- the same GEMMs as gemm_bf16_ps.hip (QKV /
 // attention_proj / FFN-1 / FFN-2 of models/transformer.py:193-206,261,266 and layers.py:590-612).
 //
-// Why a second shape of the same tile: with 8 waves (128x64 each) a K-tile costs 192 KiB of LDS
-// fragment reads and the two waves of a SIMD trade the matrix pipe at barriers; measured 1.75 us
-// per K-tile and CU against 1.0-1.1 us of MFMA time.  With 4 waves of 128x128 the fragment reads
+// Why this shape (it is the shape of the vendor library's hand-written 256x256x64 kernel): with 8
+// waves (128x64 each, gemm_bf16_ps.hip) a K-tile costs 192 KiB of LDS fragment reads and the two
+// waves of a SIMD trade the matrix pipe at barriers.  With 4 waves of 128x128 the fragment reads
 // drop to 128 KiB, each wave streams its 128 MFMAs per K-tile without handing the pipe over, and
 // the memory instructions (32 ds_read_b128 + 16 LDS-DMA per wave and K-tile) ride in the issue
 // slots between MFMAs.  256 accumulator registers + 128 fragment registers per lane: one wave per
-// SIMD owns the whole 512-entry register file.
+// SIMD owns the whole 512-entry register file.  Measured (FFN-2 shape, GRBM_GUI_ACTIVE): this
+// kernel spends MORE cycles per K-tile than the 8-wave one (3400 vs 3030; 128 bare MFMAs take
+// 2640) but the chip holds 2.05 GHz under it against 1.71 GHz: less data moved per flop, and the
+// GEMMs of the forward are power-limited.  End to end: 3050 -> 3230 seq/s (BERT-large, L = 512).
+//
+// The loads are buffer_load ... lds: one resource descriptor per operand (base = the K-tile's first
+// element), the lane's offset in a VGPR that never changes, the piece's offset in an SGPR that
+// never changes -- no vector-ALU instruction per piece.
 //
 // K-tile g lives in LDS buffer X = g & 1, g + 1 in Y.  Per K-tile (MFMA index t = 0..127, k-step
 // s = t / 64 uses the fragment registers fa[s], fb[s]):
@@ -61,22 +68,6 @@ __device__ __forceinline__ void w4_static_for(F &&f) {
 constexpr int w4_slot(int t, int t0, int step, int n) {
   return (t >= t0 && (t - t0) % step == 0 && (t - t0) / step < n) ? (t - t0) / step : -1;
 }
-// where the 16 LDS-DMA of a K-tile go (developer variants; 0 is the default)
-template <int SCHED> struct W4Sched;
-template <> struct W4Sched<0> { static constexpr int a0 = 20, as = 4, b0 = 54, bs = 4, vm = 16; };
-template <> struct W4Sched<1> { static constexpr int a0 = 20, as = 8, b0 = 56, bs = 8, vm = 12; };
-template <> struct W4Sched<2> { static constexpr int a0 = 20, as = 2, b0 = 54, bs = 2, vm = 16; };
-// 3: no LDS-DMA -- buffer_load into 64 staging VGPRs early in the K-tile, ds_write_b128 late
-template <> struct W4Sched<3> { static constexpr int a0 = -1, as = 1, b0 = -1, bs = 1, vm = 0; };
-// 4: as 3, with the XOR swizzle on the ds_write side (linear global addresses per row)
-template <> struct W4Sched<4> { static constexpr int a0 = -1, as = 1, b0 = -1, bs = 1, vm = 0; };
-// 5: as 0, wave w issues each piece w MFMAs later: the four waves reach a barrier together and
-// would otherwise all present their LDS-DMA to the CU's one address unit in the same cycles
-template <> struct W4Sched<5> { static constexpr int a0 = 20, as = 4, b0 = 54, bs = 4, vm = 16; };
-// 6: as 0 with the LINEAR LDS image: every 8-lane group of an LDS-DMA reads one 128-byte row in
-// address order (no XOR on the source side); bank conflicts are avoided by which rows share a
-// 1 KiB piece and by 32 bytes of padding per piece instead (see "LIN" in the kernel)
-template <> struct W4Sched<6> { static constexpr int a0 = 20, as = 4, b0 = 54, bs = 4, vm = 16; };
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 #define W4_BAR()                       \
@@ -87,19 +78,11 @@ template <> struct W4Sched<6> { static constexpr int a0 = 20, as = 4, b0 = 54, b
   } while (0)
 #define W4_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int ACT, bool HAS_OTHER, int ABL = 0, int SCHED = 0>
+template <int ACT, bool HAS_OTHER>
 __global__ void __launch_bounds__(256)
 dense_bf16_w4_kernel(DenseW4Args a) {
 #if __HIP_DEVICE_COMPILE__   // (the buffer-resource builtins exist in the device pass only)
-  typedef W4Sched<SCHED> SC;
-  // LIN: a half-panel is 4 groups of 4 pieces; piece (w, k) = 8 rows at k * 4224 + w * 1056 bytes
-  // (32 bytes of padding per piece, 4224 = 4 * 1056).  Tile row 32 k + r5 (r5 = 0..31) lives in
-  // piece (w = r5 & 3, k), slot t = (r5 >> 3 & 1) + 2 (r5 >> 2 & 1) + 4 (r5 >> 4): the 16 rows of
-  // an MFMA fragment then fall on 16-byte bank groups 2 (fr & 3) + 8 (fr >> 3) + chunk, which is
-  // conflict-free for every 16-lane service group of ds_read_b128, with plain chunk order.
-  constexpr bool LIN = SCHED == 6;
-  constexpr int GRP = 4224;
-  constexpr int HALF = LIN ? 4 * GRP : 128 * 128;   // bytes of one half-panel (128 rows x 64 bf16)
+  constexpr int HALF = 128 * 128;        // bytes of one half-panel (128 rows x 64 bf16)
   constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1 of one K-tile
   constexpr int SCRATCH = 2 * BUF;       // 4 x 4 KiB transpose images
   constexpr int BIAS = SCRATCH + 16384;  // the whole bias vector (N <= 8192)
@@ -133,18 +116,11 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   const int srow = lane >> 3, cpos = lane & 7;
   unsigned offA, offB;   // per-lane byte offsets inside a panel, tile- and piece-invariant
   {
-    const int row = LIN ? 16 * (srow >> 2) + wave + 4 * ((srow >> 1) & 1) + 8 * (srow & 1)
-                        : wave * 8 + srow;
-    // ABL 8: linear source (timing only); SCHED 4: linear source, swizzle applied by the ds_write
-    const int c = ((ABL & 8) || SCHED == 4 || LIN) ? cpos : cpos ^ ((row >> 1) & 7);
+    const int row = wave * 8 + srow;
+    const int c = cpos ^ ((row >> 1) & 7);
     offA = (unsigned)(row * (int)a.ldx + c * 8) * 2u;
     offB = (unsigned)(row * a.K + c * 8) * 2u;
   }
-  // The loads are buffer_load ... lds: one resource descriptor per operand (base = the K-tile's
-  // first element), the lane's offset in a VGPR that never changes, the piece's offset in an SGPR
-  // that never changes -- no vector-ALU instruction per piece (a VALU instruction between MFMAs
-  // stalls the matrix pipe on gfx950; with global_load_lds and 64-bit lane addresses the 16 pieces
-  // of a K-tile cost 0.5 us of the 2.0).
   int soffA[8], soffB[8];   // byte offsets of the pieces inside a K-tile panel (uniform)
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -156,44 +132,18 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   };
   auto stage_a = [&](char *buf, const bf16 *base, int p) {   // p = 0..7: half p>>2, quarter p&3
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsrc(base),
-        (lptr_t)(buf + (p >> 2) * HALF +
-                 (LIN ? (p & 3) * GRP + wave * 1056 : (wave + 4 * (p & 3)) * 1024)),
-        16, offA, soffA[p], 0, 0);
+        rsrc(base), (lptr_t)(buf + (p >> 2) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offA,
+        soffA[p], 0, 0);
   };
   auto stage_b = [&](char *buf, const bf16 *base, int p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsrc(base),
-        (lptr_t)(buf + (2 + (p >> 2)) * HALF +
-                 (LIN ? (p & 3) * GRP + wave * 1056 : (wave + 4 * (p & 3)) * 1024)),
-        16, offB, soffB[p], 0, 0);
-  };
-
-  // register staging (SCHED 3)
-  constexpr bool VST = SCHED == 3 || SCHED == 4;
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  u32x4 stA[8], stB[8];
-  const int wr_off =
-      SCHED == 4 ? wave * 1024 + srow * 128 + ((cpos ^ (((wave * 8 + srow) >> 1) & 7)) << 4)
-                 : wave * 1024 + lane * 16;
-  auto ld_a = [&](const bf16 *base, int p) {
-    stA[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base), offA, soffA[p], 0);
-  };
-  auto ld_b = [&](const bf16 *base, int p) {
-    stB[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base), offB, soffB[p], 0);
-  };
-  auto wr_a = [&](char *buf, int p) {
-    *reinterpret_cast<u32x4 *>(buf + (p >> 2) * HALF + (p & 3) * 4096 + wr_off) = stA[p];
-  };
-  auto wr_b = [&](char *buf, int p) {
-    *reinterpret_cast<u32x4 *>(buf + (2 + (p >> 2)) * HALF + (p & 3) * 4096 + wr_off) = stB[p];
+        rsrc(base), (lptr_t)(buf + (2 + (p >> 2)) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offB,
+        soffB[p], 0, 0);
   };
 
   // ---- fragment reads ----
   const int fr = lane & 15, fq = lane >> 4;
-  const int frag_off =
-      LIN ? (fr & 3) * 1056 + ((fr >> 3) + 2 * ((fr >> 2) & 1)) * 128 + fq * 16
-          : fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+  const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   const int a_off = wm * HALF + frag_off;
   const int b_off = (2 + wn) * HALF + frag_off;
 
@@ -201,27 +151,18 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   bf16x8 fa[2][8], fb[2][8];   // [k-step][frag]
 
   auto rd_a = [&](const char *buf, int s, int i) {
-    if constexpr (LIN)
-      fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + a_off + (i >> 1) * GRP + (i & 1) * 512 +
-                                                   s * 64);
-    else
-      fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + ((a_off + i * 2048) ^ (s << 6)));
+    fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + ((a_off + i * 2048) ^ (s << 6)));
   };
   auto rd_b = [&](const char *buf, int s, int j) {
-    if constexpr (LIN)
-      fb[s][j] = *reinterpret_cast<const bf16x8 *>(buf + b_off + (j >> 1) * GRP + (j & 1) * 512 +
-                                                   s * 64);
-    else
-      fb[s][j] = *reinterpret_cast<const bf16x8 *>(buf + ((b_off + j * 2048) ^ (s << 6)));
+    fb[s][j] = *reinterpret_cast<const bf16x8 *>(buf + ((b_off + j * 2048) ^ (s << 6)));
   };
 
   // ---- one K-tile: 128 MFMAs with the memory instructions in between (see the header) ----
   // FIRST: the tile's first K-tile starts the accumulators from the inline constant 0 (no
   // zeroing pass over 256 registers per tile).
-  auto ktile = [&](auto firstc, auto wc, char *X, char *Y, const bf16 *pA,
+  auto ktile = [&](auto firstc, char *X, char *Y, const bf16 *pA,
                    const bf16 *pB) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
-    constexpr int WSKEW = SCHED == 5 ? decltype(wc)::value : 0;
     w4_static_for<128>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
       constexpr int s = t >> 6, j = (t >> 3) & 7, i = t & 7;
@@ -235,41 +176,28 @@ dense_bf16_w4_kernel(DenseW4Args a) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
                      : "+a"(acc[j][i])
                      : "v"(fb[s][j]), "v"(fa[s][i]));
-      constexpr bool DMA = !(ABL & 1), BARS = !(ABL & 2), RD = !(ABL & 4);   // timing-only
-      if constexpr (RD && t < 16 && (t & 1)) rd_a(X, 1, t >> 1);
+      if constexpr (t < 16 && (t & 1)) rd_a(X, 1, t >> 1);
       if constexpr (t == 19) {
         W4_SB();
         W4_LGKM0();
-        if constexpr (BARS) W4_BAR();
+        W4_BAR();
       }
-      constexpr int pa = w4_slot(t - WSKEW, SC::a0, SC::as, 8);
-      constexpr int pb = w4_slot(t - WSKEW, SC::b0, SC::bs, 8);
-      if constexpr (DMA && !VST && pa >= 0) stage_a(X, pA, pa);
-      if constexpr (VST) {
-        constexpr int la = w4_slot(t, 4, 4, 8), lb = w4_slot(t, 36, 4, 8);
-        constexpr int wa = w4_slot(t, 66, 4, 8), wb = w4_slot(t, 96, 4, 8);
-        if constexpr (la >= 0) ld_a(pA, la);
-        if constexpr (lb >= 0) ld_b(pB, lb);
-        if constexpr (wa >= 0) wr_a(X, wa);
-        if constexpr (wb >= 0) wr_b(X, wb);
-      }
-      if constexpr (RD && t >= 22 && t <= 50 && ((t - 22) & 3) == 0) rd_b(X, 1, (t - 22) >> 2);
+      constexpr int pa = w4_slot(t, 20, 4, 8), pb = w4_slot(t, 54, 4, 8);
+      if constexpr (pa >= 0) stage_a(X, pA, pa);
+      if constexpr (t >= 22 && t <= 50 && ((t - 22) & 3) == 0) rd_b(X, 1, (t - 22) >> 2);
       if constexpr (t == 53) {
         W4_SB();
         W4_LGKM0();
-        if constexpr (BARS) W4_BAR();
+        W4_BAR();
       }
-      if constexpr (DMA && !VST && pb >= 0) stage_b(X, pB, pb);
-      if constexpr (t == 87 && !VST) {
+      if constexpr (pb >= 0) stage_b(X, pB, pb);
+      if constexpr (t == 87) {   // the 16 requests of this K-tile may stay in flight
         W4_SB();
-        if constexpr (DMA) {
-          if constexpr (SC::vm == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        }
-        if constexpr (BARS) W4_BAR();
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        W4_BAR();
       }
-      if constexpr (RD && t >= 88 && t <= 102 && !(t & 1)) rd_a(Y, 0, (t - 88) >> 1);
-      if constexpr (RD && t >= 104 && t <= 118 && !(t & 1)) rd_b(Y, 0, (t - 104) >> 1);
+      if constexpr (t >= 88 && t <= 102 && !(t & 1)) rd_a(Y, 0, (t - 88) >> 1);
+      if constexpr (t >= 104 && t <= 118 && !(t & 1)) rd_b(Y, 0, (t - 104) >> 1);
       W4_SB();
     });
   };
@@ -394,33 +322,18 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1, fragments of k-step 0 ----
-  if constexpr (VST) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+  for (int p = 0; p < 8; ++p) stage_a(smem, pA, p);
 #pragma unroll
-      for (int p = 0; p < 8; ++p) ld_a(pA, p);
+  for (int p = 0; p < 8; ++p) stage_b(smem, pB, p);
+  advance();
 #pragma unroll
-      for (int p = 0; p < 8; ++p) ld_b(pB, p);
+  for (int p = 0; p < 8; ++p) stage_a(smem + BUF, pA, p);
 #pragma unroll
-      for (int p = 0; p < 8; ++p) wr_a(smem + g * BUF, p);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) wr_b(smem + g * BUF, p);
-      advance();
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) stage_a(smem, pA, p);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) stage_b(smem, pB, p);
-    advance();
-#pragma unroll
-    for (int p = 0; p < 8; ++p) stage_a(smem + BUF, pA, p);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) stage_b(smem + BUF, pB, p);
-    advance();
-  }
+  for (int p = 0; p < 8; ++p) stage_b(smem + BUF, pB, p);
+  advance();
   W4_SB();
-  if constexpr (!VST) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   W4_LGKM0();   // the bias image
   W4_BAR();
 #pragma unroll
@@ -428,29 +341,21 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) rd_b(smem, 0, j);
 
-  auto stream = [&](auto wc) __attribute__((always_inline)) {
-    int par = 0;
-    for (int ti = 0; ti < n_my; ++ti) {
-      int m0, n0;
-      coords(ti, m0, n0);
-      ktile(std::true_type{}, wc, smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
+  int par = 0;
+  for (int ti = 0; ti < n_my; ++ti) {
+    int m0, n0;
+    coords(ti, m0, n0);
+    // (the first K-tile is peeled: one loop body, so that the fragment registers read at the end
+    // of a K-tile are the ones the next K-tile starts from, without copies)
+    ktile(std::true_type{}, smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
+    advance();
+    par ^= 1;
+    for (int t = 1; t < nk; ++t) {
+      ktile(std::false_type{}, smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
       advance();
       par ^= 1;
-      for (int t = 1; t < nk; ++t) {
-        ktile(std::false_type{}, wc, smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
-        advance();
-        par ^= 1;
-      }
-      drain(m0, n0);
     }
-  };
-  if constexpr (SCHED == 5) {   // one copy of the stream per wave: the skew is a compile-time slot
-    if (wave == 0) stream(std::integral_constant<int, 0>{});
-    else if (wave == 1) stream(std::integral_constant<int, 1>{});
-    else if (wave == 2) stream(std::integral_constant<int, 2>{});
-    else stream(std::integral_constant<int, 3>{});
-  } else {
-    stream(std::integral_constant<int, 0>{});
+    drain(m0, n0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two requests past the end
 #endif
@@ -477,35 +382,25 @@ static int w4_cu_count() {   // of the current device
   return n;
 }
 
-template <int ACT, bool HAS_OTHER, int ABL = 0, int SCHED = 0>
+template <int ACT, bool HAS_OTHER>
 static void launch_w4_act(const DenseW4Args &a, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * 128 + 4 * 4096 + 16384;   // 160 KiB
   static PerDeviceFlag attr;
   attr.once([&] {
-    (void)hipFuncSetAttribute((const void *)dense_bf16_w4_kernel<ACT, HAS_OTHER, ABL, SCHED>,
+    (void)hipFuncSetAttribute((const void *)dense_bf16_w4_kernel<ACT, HAS_OTHER>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int nt = a.tiles_m * a.tiles_n;
   int grid = w4_cu_count() & ~7;         // one workgroup per CU, a multiple of the 8 XCDs
   const int need = ((nt + 7) / 8) * 8;   // fewer tiles than CUs: one tile each
   if (grid > need) grid = need;
-  dense_bf16_w4_kernel<ACT, HAS_OTHER, ABL, SCHED><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
+  dense_bf16_w4_kernel<ACT, HAS_OTHER><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
 }
 
-template <int ACT, int SCHED>
+template <int ACT>
 static void launch_w4_other(const DenseW4Args &a, hipStream_t s) {
-  if (a.other) launch_w4_act<ACT, true, 0, SCHED>(a, s);
-  else launch_w4_act<ACT, false, 0, SCHED>(a, s);
-}
-
-template <int SCHED>
-static void launch_w4_sched(const DenseW4Args &a, int act, hipStream_t s) {
-  switch (act) {
-    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU, SCHED>(a, s); break;
-    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF, SCHED>(a, s); break;
-    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH, SCHED>(a, s); break;
-    default: launch_w4_other<GNLP_ACT_IDENTITY, SCHED>(a, s); break;
-  }
+  if (a.other) launch_w4_act<ACT, true>(a, s);
+  else launch_w4_act<ACT, false>(a, s);
 }
 
 void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const void *bias,
@@ -522,30 +417,12 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   const char *gm = getenv("GNLP_GROUP_M");   // developer knob
   a.group_m = gm ? atoi(gm) : 8;
   if (a.group_m < 1) a.group_m = 1;
-  const char *abl = getenv("GNLP_W4_ABL");   // TIMING-ONLY ablations (wrong results)
-  if (abl && a.other && act == GNLP_ACT_IDENTITY) {
-    switch (atoi(abl)) {
-      case 1: launch_w4_act<GNLP_ACT_IDENTITY, true, 1>(a, s); return;
-      case 2: launch_w4_act<GNLP_ACT_IDENTITY, true, 2>(a, s); return;
-      case 3: launch_w4_act<GNLP_ACT_IDENTITY, true, 3>(a, s); return;
-      case 4: launch_w4_act<GNLP_ACT_IDENTITY, true, 4>(a, s); return;
-      case 5: launch_w4_act<GNLP_ACT_IDENTITY, true, 5>(a, s); return;
-      case 7: launch_w4_act<GNLP_ACT_IDENTITY, true, 7>(a, s); return;
-      case 12: launch_w4_act<GNLP_ACT_IDENTITY, true, 12>(a, s); return;
-      case 10: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 1>(a, s); return;
-      case 20: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 2>(a, s); return;
-      case 30: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 3>(a, s); return;
-      case 40: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 4>(a, s); return;
-      case 50: launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 5>(a, s); return;
-      case 60: if (a.tiles_n * 256 <= 6144) { launch_w4_act<GNLP_ACT_IDENTITY, true, 0, 6>(a, s); return; } break;
-      default: break;
-    }
+  switch (act) {
+    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, s); break;
+    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, s); break;
+    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, s); break;
+    default: launch_w4_other<GNLP_ACT_IDENTITY>(a, s); break;
   }
-  const char *sc = getenv("GNLP_W4_SCHED");   // developer knob: LDS-DMA placement / LDS image
-  const int sched = sc ? atoi(sc) : 0;
-  if (sched == 1) launch_w4_sched<1>(a, act, s);
-  else if (sched == 6 && a.tiles_n * 256 <= 6144) launch_w4_sched<6>(a, act, s);
-  else launch_w4_sched<0>(a, act, s);
 }
 
 }  // namespace gnlp

@@ -1,5 +1,5 @@
-"""Developer tool (run under rocprofv3 --pmc GRBM_GUI_ACTIVE): FFN-2 shape on the 8-wave kernel,
-the one-wave-per-SIMD kernel and its timing-only ablations, and the vendor library."""
+"""Developer tool (run under rocprofv3 --pmc GRBM_GUI_ACTIVE by tools/w4_clock.sh): the FFN-2 shape
+on the 8-wave kernel, the one-wave-per-SIMD kernel and the vendor library's kernel."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gluon-nlp_amd'))
@@ -11,10 +11,8 @@ d.bias.data.normal_(0, 0.02)
 x = torch.randn(M, K, device='cuda').to(torch.bfloat16)
 o = torch.randn(M, N, device='cuda').to(torch.bfloat16)
 out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
-for w4, abl in (('0', ''), ('1', ''), ('1', '1'), ('1', '7'), ('1', '4')):
+for w4 in ('0', '1'):
     os.environ['GNLP_GEMM_W4'] = w4
-    if abl: os.environ['GNLP_W4_ABL'] = abl
-    else: os.environ.pop('GNLP_W4_ABL', None)
     for _ in range(25):
         d(x, other=o, out=out)
     torch.cuda.synchronize()
