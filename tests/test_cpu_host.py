@@ -221,6 +221,58 @@ def test_persistent_gemm_static_checks(tmp_path):
     assert ', 0 problems' in r.stdout
 
 
+def test_one_wave_per_simd_gemm_static_checks(tmp_path):
+    """gemm_bf16_w4.hip relies on what the compiler makes of it: the 256 accumulators must live in
+    AGPRs and nothing may spill (scratch traffic counts in vmcnt, which the kernel waits on by
+    hand), and every K-tile body must stay 128 MFMAs + 32 ds_read_b128 + 16 buffer_load-to-LDS with
+    no accumulator copies, no other vector-memory instruction and exactly one vmcnt wait,
+    `vmcnt(16)`.  Checked on the gfx950 assembly of every instantiation (hipcc cross-compiles)."""
+    hipcc = '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'gluon-nlp_amd', 'csrc', 'gemm_bf16_w4.hip')
+    asm = str(tmp_path / 'w4.s')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-S',
+                    '--cuda-device-only', '-o', asm, src], check=True, capture_output=True)
+    text = open(asm).read()
+    names = re.findall(r'\.name:\s+(_ZN4gnlp20dense_bf16_w4_kernel\w+)', text)
+    assert len(names) == 8
+    for key, want in [('vgpr_spill_count', 0), ('sgpr_spill_count', 0),
+                      ('private_segment_fixed_size', 0), ('agpr_count', 256)]:
+        vals = [int(v) for v in re.findall(r'\.%s:\s+(\d+)' % key, text)]
+        assert len(vals) == len(names) and all(v == want for v in vals), (key, vals)
+    bodies = 0
+    for name in names:
+        body = text[text.index('\n' + name + ':'):]
+        body = body[:body.index('s_endpgm')]
+        lines = [l.split(';')[0].strip() for l in body.splitlines()]
+        lines = [l for l in lines if l and not l.startswith('.') or l.startswith('.LBB')]
+        # split into straight-line runs and keep those that hold a whole K-tile (128 MFMAs)
+        run = []
+        for l in lines + ['.LBB_end:']:
+            if l.startswith('.LBB') or l.startswith('s_cbranch') or l.startswith('s_branch'):
+                mf = [x for x in run if x.startswith('v_mfma')]
+                if len(mf) >= 128:
+                    assert len(mf) == 128, (name, len(mf))
+                    ops = [x.split()[0] for x in run]
+                    assert ops.count('ds_read_b128') == 32, (name, ops.count('ds_read_b128'))
+                    dma = [x for x in run if x.startswith('buffer_load_dwordx4') and 'lds' in x]
+                    assert len(dma) == 16 and all('offen' in x for x in dma), (name, len(dma))
+                    assert ops.count('s_barrier') == 3, name
+                    vm = [x for x in run if x.startswith('s_waitcnt') and 'vmcnt' in x]
+                    assert vm == ['s_waitcnt vmcnt(16)'], (name, vm)
+                    assert not any(o.startswith('v_accvgpr') or o.startswith('scratch_') or
+                                   o.startswith('global_') or o.startswith('ds_write')
+                                   for o in ops), name
+                    valu = [o for o in ops if o.startswith('v_') and not o.startswith('v_mfma')]
+                    assert len(valu) <= 8, (name, valu)   # fragment-read bases of the two buffers
+                    bodies += 1
+                run = []
+            else:
+                run.append(l)
+    assert bodies == 2 * len(names)   # the tile's first K-tile (C = 0) and the loop body
+
+
 def test_parameter_files_round_trip(tmp_path):
     """a Gluon-style ``.params`` file (npz container keyed by the structural
     parameter names, what MXNet 2.x save_parameters writes) and a torch state_dict both load by
