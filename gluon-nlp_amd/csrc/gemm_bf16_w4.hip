@@ -78,11 +78,18 @@ constexpr int w4_slot(int t, int t0, int step, int n) {
   } while (0)
 #define W4_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int ACT, bool HAS_OTHER>
+// NJ = 16-column fragments per wave: 8 = 256x256 tiles, 6 = 256x192 tiles (each wave 128x96; the
+// B half-panels keep their 16 KiB slots and use 12 KiB of them).  The narrower tile exists for
+// N = 768 / 2304 (BERT-base, T5-base): 384 tiles of 256x256 are two rounds over 256 CUs with half
+// of them idle in the second, 512 tiles of 256x192 are two full rounds of 3/4 the work.
+template <int ACT, bool HAS_OTHER, int NJ>
 __global__ void __launch_bounds__(256)
 dense_bf16_w4_kernel(DenseW4Args a) {
 #if __HIP_DEVICE_COMPILE__   // (the buffer-resource builtins exist in the device pass only)
-  constexpr int HALF = 128 * 128;        // bytes of one half-panel (128 rows x 64 bf16)
+  static_assert(NJ == 8 || NJ == 6, "256- or 192-wide tiles");
+  constexpr int NT = 32 * NJ;            // tile width
+  constexpr int NQ = NJ / 2;             // 32-row pieces of a B half-panel per wave
+  constexpr int HALF = 128 * 128;        // bytes of one half-panel slot (128 rows x 64 bf16)
   constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1 of one K-tile
   constexpr int SCRATCH = 2 * BUF;       // 4 x 4 KiB transpose images
   constexpr int BIAS = SCRATCH + 16384;  // the whole bias vector (N <= 8192)
@@ -108,7 +115,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     const int band_h = (a.tiles_m - band_m0) < GROUP_M ? (a.tiles_m - band_m0) : GROUP_M;
     const int in_band = tile - band * GROUP_M * a.tiles_n;
     m0 = (band_m0 + in_band % band_h) * 256;
-    n0 = (in_band / band_h) * 256;
+    n0 = (in_band / band_h) * NT;
   };
 
   // ---- staging: wave w moves pieces w, w+4, w+8, w+12 (8 rows x 128 B each) of every half-panel,
@@ -121,12 +128,12 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     offA = (unsigned)(row * (int)a.ldx + c * 8) * 2u;
     offB = (unsigned)(row * a.K + c * 8) * 2u;
   }
-  int soffA[8], soffB[8];   // byte offsets of the pieces inside a K-tile panel (uniform)
+  int soffA[8], soffB[NJ];   // byte offsets of the pieces inside a K-tile panel (uniform)
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    soffA[p] = (int)(((p >> 2) * 128 + (p & 3) * 32) * a.ldx * 2);
-    soffB[p] = (int)(((p >> 2) * 128 + (p & 3) * 32) * (int64_t)a.K * 2);
-  }
+  for (int p = 0; p < 8; ++p) soffA[p] = (int)(((p >> 2) * 128 + (p & 3) * 32) * a.ldx * 2);
+#pragma unroll
+  for (int p = 0; p < NJ; ++p)
+    soffB[p] = (int)(((p / NQ) * (NT / 2) + (p % NQ) * 32) * (int64_t)a.K * 2);
   auto rsrc = [](const bf16 *base) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
   };
@@ -135,9 +142,9 @@ dense_bf16_w4_kernel(DenseW4Args a) {
         rsrc(base), (lptr_t)(buf + (p >> 2) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offA,
         soffA[p], 0, 0);
   };
-  auto stage_b = [&](char *buf, const bf16 *base, int p) {
+  auto stage_b = [&](char *buf, const bf16 *base, int p) {   // p = 0..NJ-1: half p/NQ, piece p%NQ
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsrc(base), (lptr_t)(buf + (2 + (p >> 2)) * HALF + (wave + 4 * (p & 3)) * 1024), 16, offB,
+        rsrc(base), (lptr_t)(buf + (2 + p / NQ) * HALF + (wave + 4 * (p % NQ)) * 1024), 16, offB,
         soffB[p], 0, 0);
   };
 
@@ -147,8 +154,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   const int a_off = wm * HALF + frag_off;
   const int b_off = (2 + wn) * HALF + frag_off;
 
-  f32x4 acc[8][8];   // [n-frag][m-frag]; first written by the tile's first K-tile
-  bf16x8 fa[2][8], fb[2][8];   // [k-step][frag]
+  f32x4 acc[NJ][8];   // [n-frag][m-frag]; first written by the tile's first K-tile
+  bf16x8 fa[2][8], fb[2][NJ];   // [k-step][frag]
 
   auto rd_a = [&](const char *buf, int s, int i) {
     fa[s][i] = *reinterpret_cast<const bf16x8 *>(buf + ((a_off + i * 2048) ^ (s << 6)));
@@ -163,9 +170,12 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   auto ktile = [&](auto firstc, char *X, char *Y, const bf16 *pA,
                    const bf16 *pB) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
-    w4_static_for<128>([&](auto tc) __attribute__((always_inline)) {
+    // slots (MFMA index) of barrier 2 / barrier 3; for NJ = 6 the K-tile has 96 MFMAs and the
+    // same instructions in the same order, the B runs 6 long instead of 8
+    constexpr int T2 = NJ == 8 ? 53 : 45, T3 = NJ == 8 ? 87 : 67;
+    w4_static_for<16 * NJ>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
-      constexpr int s = t >> 6, j = (t >> 3) & 7, i = t & 7;
+      constexpr int s = t / (8 * NJ), j = (t % (8 * NJ)) >> 3, i = t & 7;
       // (inline asm: the accumulators are pinned to the AGPR half of the register file; left to
       // the register allocator they wander between the halves, hundreds of copies per K-tile)
       if constexpr (FIRST && s == 0)
@@ -182,22 +192,25 @@ dense_bf16_w4_kernel(DenseW4Args a) {
         W4_LGKM0();
         W4_BAR();
       }
-      constexpr int pa = w4_slot(t, 20, 4, 8), pb = w4_slot(t, 54, 4, 8);
+      constexpr int pa = w4_slot(t, 20, 4, 8), pb = w4_slot(t, T2 + 1, 4, NJ);
+      constexpr int rb1 = w4_slot(t, 22, 4, NJ);
       if constexpr (pa >= 0) stage_a(X, pA, pa);
-      if constexpr (t >= 22 && t <= 50 && ((t - 22) & 3) == 0) rd_b(X, 1, (t - 22) >> 2);
-      if constexpr (t == 53) {
+      if constexpr (rb1 >= 0) rd_b(X, 1, rb1);
+      if constexpr (t == T2) {
         W4_SB();
         W4_LGKM0();
         W4_BAR();
       }
       if constexpr (pb >= 0) stage_b(X, pB, pb);
-      if constexpr (t == 87) {   // the 16 requests of this K-tile may stay in flight
+      if constexpr (t == T3) {   // the 8 + NJ requests of this K-tile may stay in flight
         W4_SB();
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (NJ == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         W4_BAR();
       }
-      if constexpr (t >= 88 && t <= 102 && !(t & 1)) rd_a(Y, 0, (t - 88) >> 1);
-      if constexpr (t >= 104 && t <= 118 && !(t & 1)) rd_b(Y, 0, (t - 104) >> 1);
+      constexpr int ra0 = w4_slot(t, T3 + 1, 2, 8), rb0 = w4_slot(t, T3 + 17, 2, NJ);
+      if constexpr (ra0 >= 0) rd_a(Y, 0, ra0);
+      if constexpr (rb0 >= 0) rd_b(Y, 0, rb0);
       W4_SB();
     });
   };
@@ -209,8 +222,11 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     asm volatile("" : "+v"(ln));
     const int c8 = ln & 7, rr8 = ln >> 3, dfr = ln & 15, dfq = ln >> 4;
 #pragma unroll
-    for (int hn = 0; hn < 2; ++hn) {   // 64-column halves of the wave's 128 columns
-      const int64_t n = n0 + wn * 128 + hn * 64 + c8 * 8;
+    for (int hn = 0; hn < 2; ++hn) {   // 64-column groups of the wave's 128 (96: 64 + 32) columns
+      constexpr int WCOLS = NT / 2;
+      const int nj = NJ - hn * 4 < 4 ? NJ - hn * 4 : 4;      // fragments of this group: 4 or 2
+      const bool on = c8 * 8 < nj * 16;                      // lanes that own columns of it
+      const int64_t n = n0 + wn * WCOLS + hn * 64 + (on ? c8 : 0) * 8;
       const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(smem + BIAS + n * 2);
       float bv[8];
 #pragma unroll
@@ -219,7 +235,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
       for (int sp = 0; sp < 4; ++sp) {   // two 16-row slabs per LDS round trip
         const int64_t mrow = m0 + wm * 128 + sp * 32 + rr8;
         bf16x8 o8[2][2];
-        if (HAS_OTHER) {
+        if (HAS_OTHER) {   // (lanes that are not `on` re-read column group 0: in bounds, unused)
 #pragma unroll
           for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -233,8 +249,9 @@ dense_bf16_w4_kernel(DenseW4Args a) {
           const int s = 2 * sp + q;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<f32x4 *>(scr + dfr * 256 + (((j * 4 + dfq) ^ dfr) << 4)) =
-                acc[hn * 4 + j][s];
+            if (j < nj)
+              *reinterpret_cast<f32x4 *>(scr + dfr * 256 + (((j * 4 + dfq) ^ dfr) << 4)) =
+                  acc[hn * 4 + j < NJ ? hn * 4 + j : 0][s];
           }
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
@@ -278,7 +295,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            *reinterpret_cast<bf16x8 *>(a.out + (mrow + q * 16 + it * 8) * a.ldo + n) = o;
+            if (NJ == 8 || on)
+              *reinterpret_cast<bf16x8 *>(a.out + (mrow + q * 16 + it * 8) * a.ldo + n) = o;
           }
       }
     }
@@ -310,7 +328,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 
   // ---- the bias vector goes to LDS once (zeros without a bias) ----
   const bool has_bias = a.bias != nullptr;
-  for (int i = threadIdx.x * 8; i < a.tiles_n * 256; i += 256 * 8) {
+  for (int i = threadIdx.x * 8; i < a.tiles_n * NT; i += 256 * 8) {
     bf16x8 b8;
     if (has_bias) {
       b8 = *reinterpret_cast<const bf16x8 *>(a.bias + i);
@@ -325,21 +343,22 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 #pragma unroll
   for (int p = 0; p < 8; ++p) stage_a(smem, pA, p);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) stage_b(smem, pB, p);
+  for (int p = 0; p < NJ; ++p) stage_b(smem, pB, p);
   advance();
 #pragma unroll
   for (int p = 0; p < 8; ++p) stage_a(smem + BUF, pA, p);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) stage_b(smem + BUF, pB, p);
+  for (int p = 0; p < NJ; ++p) stage_b(smem + BUF, pB, p);
   advance();
   W4_SB();
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if constexpr (NJ == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
   W4_LGKM0();   // the bias image
   W4_BAR();
 #pragma unroll
   for (int i = 0; i < 8; ++i) rd_a(smem, 0, i);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) rd_b(smem, 0, j);
+  for (int j = 0; j < NJ; ++j) rd_b(smem, 0, j);
 
   int par = 0;
   for (int ti = 0; ti < n_my; ++ti) {
@@ -364,8 +383,26 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
                                   int64_t ldother, const void *out, const void *bias,
                                   const void *other) {
-  // the same contract as the 8-wave persistent kernel
-  return mfma_bf16_dense_ps_supported(M, N, K, ldx, ldo, ldother, out, bias, other);
+  // the same contract as the 8-wave persistent kernel, N a multiple of 256 or of 192
+  const int64_t N256 = N % 256 == 0 ? N : (N % 192 == 0 ? N / 192 * 256 : N);
+  return N <= 8192 && mfma_bf16_dense_ps_supported(M, N256, K, ldx, ldo, ldother, out, bias, other);
+}
+
+// Tile width for (M, N): 256 unless N is a multiple of 192 only, or both widths are a single
+// round over the CUs and the narrower tile keeps more of them busy (T5-base, M = 16384, N = 768:
+// 192 tiles of 256 against 256 tiles of 192, +1.8 % end to end).  Balancing ROUNDS with the
+// narrower tile does not pay: at N = 768, M = 32768, 512 tiles of 192 (two full rounds of 3/4 the
+// work) ran 1.3 % slower end to end than 384 tiles of 256 (a half-empty second round) -- these
+// GEMMs are power-limited, idle CUs lift the clock of the busy ones, and the narrower tile moves
+// 17 % more bytes per flop.  GNLP_GEMM_NT=256 / 192 is the developer knob.
+static int w4_tile_width(int64_t M, int64_t N, int cus) {
+  if (N % 192 != 0) return 256;
+  if (N % 256 != 0) return 192;
+  const char *f = getenv("GNLP_GEMM_NT");
+  if (f && atoi(f) == 256) return 256;
+  if (f && atoi(f) == 192) return 192;
+  const int64_t tm = M / 256;
+  return tm * (N / 256) < cus && tm * (N / 192) <= cus ? 192 : 256;
 }
 
 static int w4_cu_count() {   // of the current device
@@ -382,25 +419,30 @@ static int w4_cu_count() {   // of the current device
   return n;
 }
 
-template <int ACT, bool HAS_OTHER>
+template <int ACT, bool HAS_OTHER, int NJ>
 static void launch_w4_act(const DenseW4Args &a, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * 128 + 4 * 4096 + 16384;   // 160 KiB
   static PerDeviceFlag attr;
   attr.once([&] {
-    (void)hipFuncSetAttribute((const void *)dense_bf16_w4_kernel<ACT, HAS_OTHER>,
+    (void)hipFuncSetAttribute((const void *)dense_bf16_w4_kernel<ACT, HAS_OTHER, NJ>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int nt = a.tiles_m * a.tiles_n;
   int grid = w4_cu_count() & ~7;         // one workgroup per CU, a multiple of the 8 XCDs
   const int need = ((nt + 7) / 8) * 8;   // fewer tiles than CUs: one tile each
   if (grid > need) grid = need;
-  dense_bf16_w4_kernel<ACT, HAS_OTHER><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
+  dense_bf16_w4_kernel<ACT, HAS_OTHER, NJ><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
 }
 
 template <int ACT>
-static void launch_w4_other(const DenseW4Args &a, hipStream_t s) {
-  if (a.other) launch_w4_act<ACT, true>(a, s);
-  else launch_w4_act<ACT, false>(a, s);
+static void launch_w4_other(const DenseW4Args &a, int nt_width, hipStream_t s) {
+  if (nt_width == 192) {
+    if (a.other) launch_w4_act<ACT, true, 6>(a, s);
+    else launch_w4_act<ACT, false, 6>(a, s);
+  } else {
+    if (a.other) launch_w4_act<ACT, true, 8>(a, s);
+    else launch_w4_act<ACT, false, 8>(a, s);
+  }
 }
 
 void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const void *bias,
@@ -413,15 +455,16 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   a.ldx = ldx; a.ldo = ldo; a.ldother = ldother;
   a.K = (int)K; a.nk = (int)(K >> 6); a.combine = combine;
   a.tiles_m = (int)(M / 256);
-  a.tiles_n = (int)(N / 256);
+  const int width = w4_tile_width(M, N, w4_cu_count() & ~7);
+  a.tiles_n = (int)(N / width);
   const char *gm = getenv("GNLP_GROUP_M");   // developer knob
   a.group_m = gm ? atoi(gm) : 8;
   if (a.group_m < 1) a.group_m = 1;
   switch (act) {
-    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, s); break;
-    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, s); break;
-    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, s); break;
-    default: launch_w4_other<GNLP_ACT_IDENTITY>(a, s); break;
+    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, width, s); break;
+    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, width, s); break;
+    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, width, s); break;
+    default: launch_w4_other<GNLP_ACT_IDENTITY>(a, width, s); break;
   }
 }
 

@@ -226,7 +226,8 @@ def test_one_wave_per_simd_gemm_static_checks(tmp_path):
     AGPRs and nothing may spill (scratch traffic counts in vmcnt, which the kernel waits on by
     hand), and every K-tile body must stay 128 MFMAs + 32 ds_read_b128 + 16 buffer_load-to-LDS with
     no accumulator copies, no other vector-memory instruction and exactly one vmcnt wait,
-    `vmcnt(16)`.  Checked on the gfx950 assembly of every instantiation (hipcc cross-compiles)."""
+    `vmcnt(16)` (256x192 tiles: 192 accumulators, 96 + 28 + 14, `vmcnt(14)`).  Checked on the
+    gfx950 assembly of every instantiation (hipcc cross-compiles)."""
     hipcc = '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
@@ -236,13 +237,18 @@ def test_one_wave_per_simd_gemm_static_checks(tmp_path):
                     '--cuda-device-only', '-o', asm, src], check=True, capture_output=True)
     text = open(asm).read()
     names = re.findall(r'\.name:\s+(_ZN4gnlp20dense_bf16_w4_kernel\w+)', text)
-    assert len(names) == 8
+    assert len(names) == 16
+    narrow = [n.endswith('Li6EEEvNS_11DenseW4ArgsE') for n in names]   # NJ = 6: 256x192 tiles
+    assert sum(narrow) == 8
     for key, want in [('vgpr_spill_count', 0), ('sgpr_spill_count', 0),
-                      ('private_segment_fixed_size', 0), ('agpr_count', 256)]:
+                      ('private_segment_fixed_size', 0)]:
         vals = [int(v) for v in re.findall(r'\.%s:\s+(\d+)' % key, text)]
         assert len(vals) == len(names) and all(v == want for v in vals), (key, vals)
+    agprs = [int(v) for v in re.findall(r'\.agpr_count:\s+(\d+)', text)]
+    assert agprs == [192 if n else 256 for n in narrow], agprs
     bodies = 0
-    for name in names:
+    for name, nar in zip(names, narrow):
+        n_mfma, n_rd, n_dma = (96, 28, 14) if nar else (128, 32, 16)
         body = text[text.index('\n' + name + ':'):]
         body = body[:body.index('s_endpgm')]
         lines = [l.split(';')[0].strip() for l in body.splitlines()]
@@ -252,15 +258,15 @@ def test_one_wave_per_simd_gemm_static_checks(tmp_path):
         for l in lines + ['.LBB_end:']:
             if l.startswith('.LBB') or l.startswith('s_cbranch') or l.startswith('s_branch'):
                 mf = [x for x in run if x.startswith('v_mfma')]
-                if len(mf) >= 128:
-                    assert len(mf) == 128, (name, len(mf))
+                if len(mf) >= n_mfma:
+                    assert len(mf) == n_mfma, (name, len(mf))
                     ops = [x.split()[0] for x in run]
-                    assert ops.count('ds_read_b128') == 32, (name, ops.count('ds_read_b128'))
+                    assert ops.count('ds_read_b128') == n_rd, (name, ops.count('ds_read_b128'))
                     dma = [x for x in run if x.startswith('buffer_load_dwordx4') and 'lds' in x]
-                    assert len(dma) == 16 and all('offen' in x for x in dma), (name, len(dma))
+                    assert len(dma) == n_dma and all('offen' in x for x in dma), (name, len(dma))
                     assert ops.count('s_barrier') == 3, name
                     vm = [x for x in run if x.startswith('s_waitcnt') and 'vmcnt' in x]
-                    assert vm == ['s_waitcnt vmcnt(16)'], (name, vm)
+                    assert vm == ['s_waitcnt vmcnt(%d)' % n_dma], (name, vm)
                     assert not any(o.startswith('v_accvgpr') or o.startswith('scratch_') or
                                    o.startswith('global_') or o.startswith('ds_write')
                                    for o in ops), name

@@ -271,6 +271,10 @@ def test_dense(nlp, dtype, M, N, K):
     (4608, 4096, 128),    # 288 tiles: workgroups with one and with two tiles, nk = 2 (minimum)
     (2048, 8192, 320),    # widest N the LDS bias image holds
     (2048, 8448, 128),    # N > 8192: one-tile-per-workgroup kernel
+    (16384, 768, 192),    # 256x192 tiles (N = 768): 256 tiles, one per workgroup
+    (32768, 768, 128),    # 256x192 tiles: 512 tiles, two per workgroup, nk = 2
+    (8448, 2304, 320),    # 256x192 tiles: 396 tiles, workgroups with one and with two
+    (8192, 960, 256),     # N a multiple of 192 only: 160 tiles of 256x192
 ])
 def test_dense_persistent(nlp, M, N, K, monkeypatch):
     """The persistent big-GEMM kernels (csrc/gemm_bf16_w4.hip, csrc/gemm_bf16_ps.hip) against the
