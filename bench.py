@@ -141,7 +141,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    dist_on = world > 1
+    # GNLP_BENCH_FORCE_DIST=1: rehearse the multi-rank control flow (process group, barriers,
+    # all-gather on the side stream, max over ranks) with a one-rank RCCL group on a 1-GPU box
+    force_dist = os.environ.get('GNLP_BENCH_FORCE_DIST') == '1'
+    dist_on = world > 1 or force_dist
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     if dist_on:
@@ -164,10 +167,13 @@ def main():
         vl[0], vl[-1] = L, 1
     else:
         vl = torch.full((B,), L, device=dev, dtype=torch.int64)   # reference harness: full
-    runner = BatchShardedEncoder(model, world_size=world, rank=rank)
+    runner = BatchShardedEncoder(model, world_size=world, rank=rank, force_collective=force_dist)
 
     def step():
         return runner.forward_local(x, vl)
+
+    def step_no_collective():   # the same forward without the all-gather: what rank 0 may run alone
+        return runner.encode_local(x, vl)
 
     if args.from_ids:
         if kind == 't5':
@@ -182,6 +188,7 @@ def main():
         def step():   # noqa: F811
             ctx, pooled = bm(ids, tts, vl)
             return ctx, pooled
+        step_no_collective = step   # noqa: F811
 
     for _ in range(args.warmup):
         step()
@@ -227,7 +234,9 @@ def main():
         # with the library's event hook armed); back-to-back launches of the kernel alone run
         # ~20 % slower (sustained matrix load -> lower clock) and are reported beside it
         ms_alone = time_dense(M, F, U, act, dtype, dev)
-        ms, n_meas = time_dense_in_situ(step, M, F, U, layers * min(args.steps, 5), dev)
+        # (rank 0 alone is in here: nothing in this block may issue a collective)
+        ms, n_meas = time_dense_in_situ(step_no_collective, M, F, U,
+                                        layers * min(args.steps, 5), dev)
         if ms is None:
             ms, n_meas = ms_alone, 20
         kflops = 2.0 * M * F * U

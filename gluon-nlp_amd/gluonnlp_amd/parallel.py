@@ -50,6 +50,10 @@ class BatchShardedEncoder:
         res = self.model(data, valid_length)
         return res[0] if isinstance(res, tuple) else res
 
+    def encode_local(self, data, valid_length):
+        """This rank's shard through the encoder, no collective (safe to call on one rank only)."""
+        return self._run(data, valid_length)
+
     def cls_rows(self, out):
         return out[:, 0, :] if self.layout == 'NT' else out[0]
 
