@@ -27,6 +27,8 @@
 //   t  87      vmcnt(16) (all of g + 1 has landed for this wave), barrier 3: Y is complete
 //   t  88..118 ds_read A and B fragments of k-step 0 of g + 1 from Y
 // so a K-tile is requested almost two K-tiles before its first use out of two 64 KiB buffers.
+// (256x192 tiles, NJ = 6: 96 MFMAs, k-step s = t / 48; the B runs are 6 long, barrier 2 at t 45,
+// LDS-DMA B at t 46..66, vmcnt(14) + barrier 3 at t 67, fragment reads of g + 1 at t 68..94.)
 // The stream of K-tiles runs across the tiles of the workgroup; between the last K-tile of a tile
 // and the first of the next the 256 accumulators are drained (bias, activation, residual, bf16
 // store in full 128-byte lines through a 4 KiB LDS transpose image per wave) while the next

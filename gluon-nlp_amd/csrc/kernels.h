@@ -117,7 +117,8 @@ void launch_mfma_bf16_dense_ps(void *out, const void *x, const void *w, const vo
                                const void *other, int combine, int act, int64_t M, int64_t N,
                                int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
                                hipStream_t s);
-// One-wave-per-SIMD form (gemm_bf16_w4.hip): 4 waves of 128x128, same contract as the _ps kernel.
+// One-wave-per-SIMD form (gemm_bf16_w4.hip): 4 waves of 128x128, same contract as the _ps kernel,
+// N a multiple of 256 or of 192 (256x192 tiles, 4 waves of 128x96).
 bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
                                   int64_t ldother, const void *out, const void *bias,
                                   const void *other);
