@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- BERT-large encoder forward (L=512, bf16) sequences/s on N MI355X.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torchrun, one
-rank per GPU).  A step = one forward of the 24-layer encoder stack (the hot path of
+Contract: ``python bench.py --gpus N --steps K --warmup W``.  ``--gpus N`` MEANS N: under torchrun
+(WORLD_SIZE set) the world size must equal N or the run exits non-zero; started plainly with
+N > 1 the parent -- before it touches a GPU -- starts N ranks through ``torch.distributed.run``
+(one per GPU, 127.0.0.1 rendezvous) and exits with their status; fewer than N visible GPUs is an
+error, never a silent 1-GPU run.  The printed ``n_gpus`` is the live process group's size and
+``rccl_ranks`` an all-reduce of ones over it.  A step = one forward of the 24-layer encoder stack (the hot path of
 BASELINE.json) over one synthetic batch already resident in HBM; with N>1 the batch is sharded
 (weak scaling, B=64 per GPU) and the CLS rows are all-gathered over RCCL each step.
 Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel (the FFN-1
@@ -116,10 +120,52 @@ def cpu_baseline(kind, U, H, F, layers, L, eps, sample_b):
         cores = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
     except Exception:
         cores = int(os.environ.get('OMP_NUM_THREADS', '1'))
-    return {'value': sample_b / dt, 'unit': 'sequences/s', 'cores': int(cores), 'kind': 'port',
+    return {'value': sample_b / dt, 'unit': 'sequences/s', 'cores': int(cores),
+            'host_cpu_count': os.cpu_count(), 'kind': 'port',
             'sample': '1 forward of B={} sequences (L={}, {} layers, fp32 numpy restatement of '
                       'the reference op sequence; not MXNet), {:.1f} s'.format(sample_b, L, layers,
                                                                                dt)}
+
+
+def resolve_launch(gpus, env, visible_gpus):
+    """Decide how this process runs.  -> ('rank', world) when it is one rank of a launched job (or
+    the single-GPU case), ('spawn', gpus) when it must start ``gpus`` ranks itself.  Raises
+    SystemExit with a message when --gpus disagrees with the launcher or with the machine."""
+    if gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1 (got {})'.format(gpus))
+    ws = env.get('WORLD_SIZE')
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit('bench.py: --gpus {} but the launcher started WORLD_SIZE={} ranks; '
+                             'refusing to report a {}-GPU number'.format(gpus, ws, gpus))
+        return 'rank', gpus
+    if gpus == 1:
+        return 'rank', 1
+    if visible_gpus < gpus:
+        raise SystemExit('bench.py: --gpus {} but only {} GPU(s) are visible; refusing to run '
+                         'fewer ranks than asked'.format(gpus, visible_gpus))
+    return 'spawn', gpus
+
+
+def spawn_ranks(gpus, argv):
+    """Start ``gpus`` ranks of this script through torch.distributed.run as a CHILD process (this
+    process has not initialised the GPU and never replaces itself) and return its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+           str(gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
+
+
+def count_ranks(dist, device):
+    """All-reduce of ones over the live process group: what the collective backend really spans."""
+    t = torch.ones(1, device=device, dtype=torch.float32)
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
 
 
 def main():
@@ -138,7 +184,10 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=12)   # ~13 s of host work
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    # decided before anything touches a GPU (device_count() does not initialise it)
+    mode, world = resolve_launch(args.gpus, os.environ, torch.cuda.device_count())
+    if mode == 'spawn':
+        sys.exit(spawn_ranks(world, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     # GNLP_BENCH_FORCE_DIST=1: rehearse the multi-rank control flow (process group, barriers,
@@ -151,6 +200,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
+        if dist.get_world_size() != world:
+            raise SystemExit('bench.py: process group has {} ranks, --gpus {}'.format(
+                dist.get_world_size(), world))
+        rccl_ranks = count_ranks(dist, dev)
+    else:
+        rccl_ranks = 1
 
     kind, U, H, F, layers, L, B, eps = CONFIGS[args.config]
     if args.batch:
@@ -167,7 +222,10 @@ def main():
         vl[0], vl[-1] = L, 1
     else:
         vl = torch.full((B,), L, device=dev, dtype=torch.int64)   # reference harness: full
-    runner = BatchShardedEncoder(model, world_size=world, rank=rank, force_collective=force_dist)
+    # overlap=True: the all-gather of step i runs beside the forward of step i + 1 (its consumer
+    # would call wait_gather(); the timed region ends with one, so every gather is inside it)
+    runner = BatchShardedEncoder(model, world_size=world, rank=rank, force_collective=force_dist,
+                                 overlap=True)
 
     def step():
         return runner.forward_local(x, vl)
@@ -199,6 +257,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    runner.wait_gather()
     torch.cuda.synchronize(dev)
     if dist_on:
         dist.barrier()
@@ -253,7 +312,9 @@ def main():
             'metric': ('BERT-large encoder fwd seqs/s L=512' if args.config == 'bert_large'
                        else '{} encoder fwd seqs/s L={}'.format(args.config, L)) +
                       (' (token ids -> pooled output)' if args.from_ids else ''),
-            'value': seqs, 'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps,
+            'value': seqs, 'unit': 'sequences/s',
+            'n_gpus': dist.get_world_size() if dist_on else 1, 'rccl_ranks': rccl_ranks,
+            'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -15,6 +16,46 @@
 #include "kernels.h"
 
 using namespace gnlp;
+
+namespace gnlp {
+namespace {
+Knobs g_knobs;
+std::atomic<int> g_knobs_ready{0};
+int env_int(const char *name, int dflt, int lo, int hi) {
+  const char *e = getenv(name);
+  if (!e || !*e) return dflt;
+  char *end = nullptr;
+  const long v = strtol(e, &end, 10);
+  if (end == e) return dflt;
+  return v < lo ? lo : (v > hi ? hi : (int)v);
+}
+bool env_on(const char *name) {   // on unless set to something starting with '0'
+  const char *e = getenv(name);
+  return !(e && e[0] == '0');
+}
+}  // namespace
+void reload_knobs() {
+  Knobs k;
+  k.group_m = env_int("GNLP_GROUP_M", 8, 1, 64);
+  const int tile = env_int("GNLP_GEMM_TILE", 0, 0, 256);
+  k.gemm_tile = (tile == 128 || tile == 256) ? tile : 0;
+  k.gemm_pp = env_on("GNLP_GEMM_PP");
+  k.gemm_ps = env_on("GNLP_GEMM_PS");
+  k.gemm_w4 = env_on("GNLP_GEMM_W4");
+  const int nt = env_int("GNLP_GEMM_NT", 0, 0, 256);
+  k.gemm_nt = (nt == 192 || nt == 256) ? nt : 0;
+  k.gemm_krev = env_on("GNLP_GEMM_KREV");
+  k.norm_nt = env_on("GNLP_NORM_NT");
+  const char *mv = getenv("GNLP_NORM_MAXV");
+  k.norm_full = mv && mv[0] == 'f';
+  g_knobs = k;
+  g_knobs_ready.store(1, std::memory_order_release);
+}
+const Knobs &knobs() {
+  if (!g_knobs_ready.load(std::memory_order_acquire)) reload_knobs();
+  return g_knobs;
+}
+}  // namespace gnlp
 
 namespace {
 
@@ -216,6 +257,16 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
   return check_launch("unfused attention");
 }
 
+// Whether the stack drivers' own attention call (packed QKV in the workspace, no scores / weights
+// wanted, bias -- if any -- with unit key stride) takes the fused kernel: the SAME conditions
+// fused_attn_supported() checks on the real descriptor, given that the drivers require a
+// 256-byte aligned workspace and build every stride as a multiple of 8 elements.
+bool stack_attn_fuses(int dtype, int64_t B, int64_t H, int64_t dk, int64_t qkv_row_elems,
+                      int64_t ctx_row_elems) {
+  return dtype == GNLP_BF16 && dk == 64 && B <= 65535 && H <= 65535 && qkv_row_elems % 8 == 0 &&
+         ctx_row_elems % 8 == 0;
+}
+
 // ---- FFN ---------------------------------------------------------------------------------------
 struct FfnWs { size_t normed, hidden, gate, total; };
 FfnWs ffn_ws(const gnlp_ffn_cfg *c, int64_t rows) {
@@ -298,7 +349,7 @@ EncWs enc_ws(const gnlp_encoder_cfg *c, int64_t B, int64_t L, bool want_weights)
   gnlp_attn_desc d;
   memset(&d, 0, sizeof(d));
   d.B = B; d.H = c->heads; d.Lq = L; d.Lm = L; d.dk = d.dv = U / (c->heads ? c->heads : 1);
-  const bool fused = !want_weights && c->dtype == GNLP_BF16 && d.dk == 64 && (U % 8 == 0);
+  const bool fused = !want_weights && stack_attn_fuses(c->dtype, B, c->heads, d.dk, 3 * U, U);
   off += attn_ws_bytes(&d, c->dtype, false, want_weights, fused);
   w.ffn = off;
   gnlp_ffn_cfg f = ffn_cfg_of(c);
@@ -315,6 +366,7 @@ int encoder_layer_impl(void *out, const void *x, const gnlp_encoder_layer_params
   const EncWs w = enc_ws(c, B, L, attn_w_out != nullptr);
   REQUIRE(ws && ws_bytes >= w.total, "encoder workspace too small: need %zu bytes, got %zu",
           w.total, ws_bytes);
+  REQUIRE((uintptr_t)ws % 256 == 0, "workspace must be 256-byte aligned");
   char *base = (char *)ws;
   const size_t e = esize(c->dtype);
   int rc;
@@ -372,7 +424,8 @@ int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
 // =================================================================================================
 extern "C" {
 
-int gnlp_version(void) { return 100; }
+int gnlp_version(void) { return 200; }
+void gnlp_reload_knobs(void) { reload_knobs(); }
 const char *gnlp_last_error(void) { return g_err.c_str(); }
 int gnlp_device_count(void) {
   int n = 0;
@@ -521,7 +574,7 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
   REQUIRE(!mask || mask_stride, "mask given without strides");
   REQUIRE(!edge_scores || edge_stride, "edge_scores given without strides");
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
-  REQUIRE(d->B * d->H < 65536 * 16, "batch*heads too large");
+  REQUIRE(d->B * d->H <= 0x7fffffffLL, "batch*heads too large");
   if (d->B * d->H * d->Lq * d->dv == 0) return GNLP_OK;
   REQUIRE(ctx && q && k && v, "NULL tensor");
   return attn_impl(ctx, scores_out, weights_out, q, k, v, d, dtype, mask, mask_stride,
@@ -728,7 +781,7 @@ T5Ws t5_ws(const gnlp_t5_cfg *c, int64_t B, int64_t L) {
   gnlp_attn_desc d;
   memset(&d, 0, sizeof(d));
   d.B = B; d.H = c->heads; d.Lq = L; d.Lm = L; d.dk = d.dv = c->d_kv;
-  const bool fused = c->dtype == GNLP_BF16 && c->d_kv == 64;
+  const bool fused = stack_attn_fuses(c->dtype, B, c->heads, c->d_kv, 3 * inner, inner);
   size_t attn = attn_ws_bytes(&d, c->dtype, false, false, fused);
   gnlp_ffn_cfg f = t5_ffn_cfg(c);
   size_t ffn = ffn_ws(&f, M).total;
@@ -762,6 +815,9 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
   REQUIRE(workspace && workspace_bytes >= w.total + 2 * act_bytes,
           "t5 workspace too small: need %zu bytes, got %zu", w.total + 2 * act_bytes,
           workspace_bytes);
+  REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+  REQUIRE(!position_bias || (uintptr_t)position_bias % esize(cfg->dtype) == 0,
+          "position_bias is not element aligned");
   hipStream_t s = S(stream);
   char *base = (char *)workspace;
   void *pp[2] = {base + w.total, base + w.total + act_bytes};

@@ -192,16 +192,20 @@ attn_fwd_bf16_d64(FusedAttn a) {
     // multiply; p is then bounded by 2^THR, harmless in bf16 (same relative precision).
     const int64_t kbase_idx = (int64_t)tile * KV_TILE;
     const bool tail = DENSE_MASK || !rows_all_ok || (kbase_idx + KV_TILE > kv_len);
-    if (HAS_BIAS) {  // host guarantees unit key stride and Lm % 4 == 0; loads may be unaligned
+    if (HAS_BIAS) {  // host guarantees unit key stride; loads may be unaligned
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int64_t j0 = kbase_idx + kb * 32 + g * 8 + hh * 4;
-          if (j0 < a.Lm) {
+          if (j0 + 4 <= a.Lm) {
             bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(brow + j0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sacc[kb][g * 4 + e] += (float)b4[e];
+          } else if (j0 < a.Lm) {   // the last 1-3 keys of a row whose length is not a multiple of 4
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (j0 + e < a.Lm) sacc[kb][g * 4 + e] += (float)brow[j0 + e];
           }
         }
     }
@@ -334,10 +338,10 @@ bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv) {
   for (int e = 0; e < 3; ++e)
     if (a.os[e] % 8 != 0) return false;
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 != 0) return false;
-  if (a.bias) {  // vector loads of 4 consecutive keys of the bias row: unit key stride, rows a
-    // multiple of 4 keys long; any row / head / batch stride (the Toeplitz table of the T5 stack
-    // has row stride -1: its 8-byte loads are unaligned, which global memory allows)
-    if (a.bs[3] != 1 || a.Lm % 4 != 0 || (uintptr_t)a.bias % 2 != 0) return false;
+  if (a.bias) {  // vector loads of 4 consecutive keys of the bias row: unit key stride; any row /
+    // head / batch stride (the Toeplitz table of the T5 stack has row stride -1: its 8-byte loads
+    // are unaligned, which global memory allows); the last 1-3 keys of a row are read one by one
+    if (a.bs[3] != 1 || (uintptr_t)a.bias % 2 != 0) return false;
   }
   if ((uintptr_t)a.o % 16 != 0) return false;
   return true;

@@ -189,9 +189,7 @@ static void launch_act(const DenseArgs &a0, hipStream_t s) {
   DenseArgs a = a0;
   a.tiles_m = (int)((a.M + BM - 1) / BM);
   a.tiles_n = (int)((a.N + BN - 1) / BN);
-  const char *gm = getenv("GNLP_GROUP_M");   // developer knob
-  a.group_m = gm ? atoi(gm) : 8;
-  if (a.group_m < 1) a.group_m = 1;
+  a.group_m = knobs().group_m;
   constexpr int LDS = 2 * (BM + BN) * 128;
   static PerDeviceFlag attr;
   attr.once([&] {
@@ -226,23 +224,20 @@ void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void 
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.ldother = ldother;
   a.act = act; a.combine = combine; a.tiles_m = a.tiles_n = 0;
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-  const char *force = getenv("GNLP_GEMM_TILE");   // developer knob: "128" / "256"
+  const Knobs &kn = knobs();   // developer knobs, read once per process (kernels.h)
   // 256x256 tiles once they fill at least half of the 256 CUs (measured on T5-base, 192 tiles per
   // GEMM: +25 % end to end over 768 tiles of 128x128)
-  const bool big = force ? (force[0] == '2') : (t256 >= 128 && M >= 256 && N >= 256);
-  const char *pp = getenv("GNLP_GEMM_PP");         // developer knob: "0" = plain 2-phase loop
-  const char *ps = getenv("GNLP_GEMM_PS");         // developer knob: "0" = one tile per workgroup
-  // one wave per SIMD (gemm_bf16_w4.hip) unless GNLP_GEMM_W4=0 (developer knob): more cycles per
-  // K-tile than the 8-wave kernel but a third less LDS traffic, and the chip holds a higher clock
-  // under it: 3050 -> 3230 seq/s on the BERT-large forward
-  const char *w4 = getenv("GNLP_GEMM_W4");
-  if (big && !(w4 && w4[0] == '0') && !(pp && pp[0] == '0') && !(ps && ps[0] == '0') &&
+  const bool big = kn.gemm_tile ? (kn.gemm_tile == 256) : (t256 >= 128 && M >= 256 && N >= 256);
+  // one wave per SIMD (gemm_bf16_w4.hip) unless GNLP_GEMM_W4=0: more cycles per K-tile than the
+  // 8-wave kernel but a third less LDS traffic, and the chip holds a higher clock under it:
+  // 3050 -> 3230 seq/s on the BERT-large forward
+  if (big && kn.gemm_w4 && kn.gemm_pp && kn.gemm_ps &&
       mfma_bf16_dense_w4_supported(M, N, K, ldx, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_w4(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
-  else if (big && !(pp && pp[0] == '0') && !(ps && ps[0] == '0') &&
+  else if (big && kn.gemm_pp && kn.gemm_ps &&
       mfma_bf16_dense_ps_supported(M, N, K, ldx, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_ps(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
-  else if (big && !(pp && pp[0] == '0') &&
+  else if (big && kn.gemm_pp &&
       mfma_bf16_dense_pp_supported(N, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_pp(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
   else if (big)

@@ -496,9 +496,7 @@ void launch_mfma_bf16_dense_ps(void *out, const void *x, const void *w, const vo
   a.K = (int)K; a.nk = (int)(K >> 6); a.combine = combine;
   a.tiles_m = (int)(M / 256);
   a.tiles_n = (int)(N / 256);
-  const char *gm = getenv("GNLP_GROUP_M");   // developer knob
-  a.group_m = gm ? atoi(gm) : 8;
-  if (a.group_m < 1) a.group_m = 1;
+  a.group_m = knobs().group_m;
   switch (act) {
     case GNLP_ACT_RELU: launch_ps_other<GNLP_ACT_RELU>(a, s); break;
     case GNLP_ACT_GELU_ERF: launch_ps_other<GNLP_ACT_GELU_ERF>(a, s); break;

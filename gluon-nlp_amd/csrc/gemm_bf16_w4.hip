@@ -400,9 +400,7 @@ bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, 
 static int w4_tile_width(int64_t M, int64_t N, int cus) {
   if (N % 192 != 0) return 256;
   if (N % 256 != 0) return 192;
-  const char *f = getenv("GNLP_GEMM_NT");
-  if (f && atoi(f) == 256) return 256;
-  if (f && atoi(f) == 192) return 192;
+  if (knobs().gemm_nt) return knobs().gemm_nt;
   const int64_t tm = M / 256;
   return tm * (N / 256) < cus && tm * (N / 192) <= cus ? 192 : 256;
 }
@@ -459,9 +457,7 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   a.tiles_m = (int)(M / 256);
   const int width = w4_tile_width(M, N, w4_cu_count() & ~7);
   a.tiles_n = (int)(N / width);
-  const char *gm = getenv("GNLP_GROUP_M");   // developer knob
-  a.group_m = gm ? atoi(gm) : 8;
-  if (a.group_m < 1) a.group_m = 1;
+  a.group_m = knobs().group_m;
   switch (act) {
     case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, width, s); break;
     case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, width, s); break;

@@ -18,9 +18,13 @@ generic_gemm_kernel(GenericGemm g) {
   __shared__ float As[16][64 + 4];
   __shared__ float Bs[16][64 + 4];
   const int tid = threadIdx.x;
-  const int64_t bz = blockIdx.z;
+  // grid.y / grid.z are capped at 65535: a block walks the batches / row tiles beyond the cap
+  // (block-uniform loops, so the barriers inside stay legal)
+  const int64_t nbatch = g.nb0 * g.nb1, mtiles = (g.M + 63) / 64;
+  for (int64_t bz = blockIdx.z; bz < nbatch; bz += gridDim.z)
+  for (int64_t mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
   const int64_t b0 = bz / g.nb1, b1 = bz % g.nb1;
-  const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+  const int64_t m0 = mt * 64, n0 = (int64_t)blockIdx.x * 64;
   const TI *A = (const TI *)g.A + b0 * g.sAb0 + b1 * g.sAb1;
   const TI *Bm = (const TI *)g.Bm + b0 * g.sBb0 + b1 * g.sBb1;
   const int tx = tid & 15, ty = tid >> 4;  // thread owns rows ty*4.., cols tx*4..
@@ -86,11 +90,14 @@ generic_gemm_kernel(GenericGemm g) {
       C[m * g.sCm + n] = from_f32<TO>(v);
     }
   }
+  }
 }
 
 void launch_generic_gemm(const GenericGemm &g, hipStream_t s) {
   if (g.M == 0 || g.N == 0 || g.nb0 * g.nb1 == 0) return;
-  dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(g.nb0 * g.nb1));
+  const int64_t mt = (g.M + 63) / 64, nb = g.nb0 * g.nb1;
+  dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)(mt < 65535 ? mt : 65535),
+            (unsigned)(nb < 65535 ? nb : 65535));
   if (g.in_dtype == GNLP_BF16 && g.out_dtype == GNLP_BF16)
     generic_gemm_kernel<bf16, bf16><<<grid, 256, 0, s>>>(g);
   else if (g.in_dtype == GNLP_BF16)

@@ -25,6 +25,23 @@ struct PerDeviceFlag {
 };
 
 
+// Developer knobs (GNLP_* environment variables), read ONCE per process into this struct -- the
+// launch paths never call getenv.  gnlp_reload_knobs() (C ABI) re-reads them: tests and A/B
+// scripts that flip a knob mid-process call it.  Values are clamped where they index anything.
+struct Knobs {
+  int group_m;      // GNLP_GROUP_M: tile-walk band height, clamped to [1, 64]; default 8
+  int gemm_tile;    // GNLP_GEMM_TILE: 0 = by shape, 128 / 256 forced
+  bool gemm_pp;     // GNLP_GEMM_PP=0: plain 2-phase loop instead of the ping-pong kernels
+  bool gemm_ps;     // GNLP_GEMM_PS=0: one tile per workgroup instead of the persistent kernels
+  bool gemm_w4;     // GNLP_GEMM_W4=0: the 8-wave persistent kernel instead of one wave per SIMD
+  int gemm_nt;      // GNLP_GEMM_NT: 0 = by shape, 192 / 256 forced tile width
+  bool gemm_krev;   // GNLP_GEMM_KREV=0: every tile walks K forwards (see gemm_bf16_w4.hip)
+  bool norm_nt;     // GNLP_NORM_NT=0: plain instead of non-temporal loads in the norm kernel
+  bool norm_full;   // GNLP_NORM_MAXV=f: always the full-width register image
+};
+const Knobs &knobs();
+void reload_knobs();
+
 // relative_position_bucket thresholds (see elementwise.hip); passed by value as a kernel argument
 struct BucketTable {
   int bidirectional;

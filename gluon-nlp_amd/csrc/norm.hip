@@ -165,11 +165,10 @@ static void norm_t(void *out, const void *x, const void *residual, const void *g
                  (uintptr_t)(residual ? residual : x);
   const bool vec = (C % N == 0) && (C <= 64 * N * MAXV) && (al % 16 == 0);
   if (vec) {
-    const char *e_nt = getenv("GNLP_NORM_NT"), *e_mv = getenv("GNLP_NORM_MAXV");
     // x / residual are read once here and never again: non-temporal loads keep them from
     // displacing what the next GEMM re-reads (+0.45 % on the BERT-large forward, 4 of 4 A / B runs)
-    const bool nt = !(e_nt && e_nt[0] == '0');
-    const bool small = !(e_mv && e_mv[0] == 'f') && C <= 64 * N * (MAXV / 2);
+    const bool nt = knobs().norm_nt;
+    const bool small = !knobs().norm_full && C <= 64 * N * (MAXV / 2);
 #define GNLP_NORM_LAUNCH(MV, NTV)                                                                \
   norm_vec_kernel<T, MV, NTV><<<grid, 256, 0, s>>>((T *)out, (const T *)x, (const T *)residual,  \
                                                    (const T *)gamma, (const T *)beta, kind, eps, \

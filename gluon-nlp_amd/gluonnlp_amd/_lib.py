@@ -69,6 +69,7 @@ PROTOTYPES = {
     'gnlp_version': (c_int, []),
     'gnlp_last_error': (c_char_p, []),
     'gnlp_device_count': (c_int, []),
+    'gnlp_reload_knobs': (None, []),
     'gnlp_gen_self_attn_mask': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int,
                                         c_void_p]),
     'gnlp_gen_mem_attn_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
@@ -157,3 +158,13 @@ def check(rc):
     if rc != 0:
         msg = load().gnlp_last_error()
         raise GnlpError('gluonnlp_amd error {}: {}'.format(rc, (msg or b'').decode()))
+
+
+def set_knob(name, value):
+    """Developer helper: set (or, with None, unset) a GNLP_* environment knob and make the library
+    re-read its knobs (they are read once per process, never on a launch path)."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    load().gnlp_reload_knobs()

@@ -38,17 +38,23 @@ def as_tensor(x):
 
 
 def like_caller(out, ref):
-    """Return ``out`` (a torch tensor) in the framework of ``ref``."""
+    """Return ``out`` (a torch tensor) in the framework of ``ref``.
+
+    Contract: a ``torch.Tensor`` caller gets a ``torch.Tensor``; a caller whose top-level module
+    (``mxnet`` -> ``mx.np``, ``cupy``, ``jax.numpy`` ...) exposes ``from_dlpack`` gets the output
+    through that function (zero-copy; its errors propagate -- nothing is swallowed); a caller type
+    with no such module function (a bare ``__dlpack__`` provider) gets the ``torch.Tensor``, which
+    itself implements ``__dlpack__`` / ``__dlpack_device__``."""
     if ref is None or isinstance(ref, torch.Tensor):
         return out
-    mod = type(ref).__module__.split('.')[0]
-    try:
-        import importlib
-        m = importlib.import_module(mod)
-        conv = getattr(m, 'from_dlpack', None) or getattr(getattr(m, 'np', None), 'from_dlpack')
-        return conv(out)
-    except Exception:
+    import sys
+    mod = sys.modules.get(type(ref).__module__.split('.')[0])
+    conv = getattr(mod, 'from_dlpack', None)
+    if conv is None:
+        conv = getattr(getattr(mod, 'np', None), 'from_dlpack', None)
+    if conv is None:
         return out
+    return conv(out)
 
 
 def require_device(*tensors):
@@ -96,11 +102,13 @@ _WS = {}
 
 
 def workspace(dev, nbytes):
-    """Grow-only per-device scratch buffer (reused by every call on the current stream)."""
+    """Grow-only scratch buffer per (device, stream): every C call enqueues on the current stream,
+    so two streams never share scratch, and a buffer that grows is released to the caching
+    allocator under the stream it was allocated (and only ever used) on."""
     nbytes = int(nbytes)
     if nbytes == 0:
         return None
-    key = (dev.type, dev.index)
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -26,9 +26,12 @@ def _axes(layout):
 
 def _tag(mask, vl, kind):
     """Remember how a mask was generated so the layers can evaluate the predicate in-kernel
-    instead of re-reading (B, L, L) bytes per head.  Guarded by the tensor's version counter:
-    an in-place edit of the mask invalidates the tag."""
-    mask._gnlp_vl = vl
+    instead of re-reading (B, L, L) bytes per head.  The tag holds a PRIVATE copy of
+    ``valid_length`` (B integers): the mask bytes alone define attention in the reference
+    (models/transformer.py:234-265), so an in-place edit of the caller's ``valid_length`` after the
+    mask was built must not change what the layers compute.  An in-place edit of the mask itself
+    invalidates the tag (version counter)."""
+    mask._gnlp_vl = vl.clone() if vl is not None else None
     mask._gnlp_kind = kind
     mask._gnlp_version = mask._version
     return mask

@@ -1,7 +1,8 @@
 """TransformerEncoderLayer / TransformerEncoder -- mirrors the encoder half of
 ``gluonnlp/models/transformer.py`` (reference src/gluonnlp/models/transformer.py:136-385) --
 and, composed from the same kernels, the forward of TransformerDecoderLayer /
-TransformerDecoder (:389-598, :738-840).  Incremental decoding is not built."""
+TransformerDecoder (:389-598, :738-840), including incremental decoding with key / value caches
+(TransformerDecoderLayer.incremental_decode, :599-737)."""
 import ctypes
 
 import torch

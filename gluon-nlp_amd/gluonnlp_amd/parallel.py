@@ -2,7 +2,10 @@
 per sequence and LayerNorm per token), one process per GPU, weights replicated.  The only exchange
 is an all-gather of the CLS rows ``(B_local, units)`` (what ``BertModel.apply_pooling`` consumes,
 reference src/gluonnlp/models/bert.py:506-529) over RCCL/xGMI -- <= 256 KiB per rank, latency
-bound, issued on a side stream so it overlaps the next batch.  No data-path collective otherwise.
+bound, issued on a side stream.  By default the main stream waits for it (the gathered rows are
+safe to read at once); with ``overlap=True`` it does not: the next batch's forward starts while
+the gather runs and the consumer calls ``wait_gather()`` before reading the gathered rows.  No
+data-path collective otherwise.
 (Reference analogue: hvd.allgather of eval outputs, scripts/machine_translation/
 train_transformer.py:790-801.)"""
 import torch
@@ -26,7 +29,7 @@ class BatchShardedEncoder:
     all-gather even when ``world_size == 1`` (a one-rank RCCL group exercises the GPU path)."""
 
     def __init__(self, model=None, world_size=1, rank=0, layout='NT', compute=None, group=None,
-                 force_collective=False):
+                 force_collective=False, overlap=False):
         self.model = model
         self.world_size = world_size
         self.rank = rank
@@ -35,6 +38,8 @@ class BatchShardedEncoder:
         self._group = group
         self._side = None
         self._force = force_collective   # run the gather even with one rank (tests)
+        self._overlap = overlap          # do not make the main stream wait for the gather
+        self._pending = None             # event of the last gather not yet waited for
 
     # ---- sharding ----------------------------------------------------------------------------
     def shard(self, data, valid_length):
@@ -81,13 +86,22 @@ class BatchShardedEncoder:
                 dist.all_gather_into_tensor(gathered, cls, group=self._group)
             cls.record_stream(self._side)
             gathered.record_stream(self._side)
-            # the consumer of `gathered` must wait for the side stream
-            torch.cuda.current_stream(cls.device).wait_stream(self._side)
+            if self._overlap:
+                # the next forward may start now; whoever reads `gathered` calls wait_gather()
+                self._pending = self._side.record_event()
+            else:
+                torch.cuda.current_stream(cls.device).wait_stream(self._side)
         else:
             parts = [torch.empty_like(cls) for _ in range(self.world_size)]
             dist.all_gather(parts, cls, group=self._group)
             gathered = torch.cat(parts, 0)
         return out, gathered
+
+    def wait_gather(self):
+        """Make the current stream wait for the last all-gather issued with ``overlap=True``."""
+        if self._pending is not None:
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
 
     def forward(self, data, valid_length):
         """Global batch in, (out_local, cls of the WHOLE batch in global order) out."""
@@ -96,6 +110,7 @@ class BatchShardedEncoder:
         x, vl = self.shard(data, valid_length)
         cap = shard_bounds(B, self.world_size, 0)[1]
         out, g = self.forward_local(x, vl, max_local=cap)
+        self.wait_gather()
         if self.world_size == 1:
             return out, g
         rows = []

@@ -13,7 +13,10 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call is
  *    asynchronous on that stream and allocates nothing;
  *  - return value 0 = ok, <0 = error; gnlp_last_error() gives the thread-local message;
- *  - the library is reentrant per stream and keeps no global state.
+ *  - the library is reentrant per stream.  Its only process-global state: the developer knobs
+ *    (GNLP_* environment variables, read ONCE on first use -- never on a launch path -- and
+ *    re-read only by gnlp_reload_knobs()), per-device kernel attributes set once, and the
+ *    measurement hook at the end of this file (off unless armed).
  */
 #ifndef GLUONNLP_AMD_H_
 #define GLUONNLP_AMD_H_
@@ -50,6 +53,10 @@ int gnlp_version(void);
 const char *gnlp_last_error(void);
 /* Number of HIP devices visible / name of the current one (diagnostics only). */
 int gnlp_device_count(void);
+/* Re-read the GNLP_* developer knobs from the environment (no counterpart in the reference; for
+ * tests and A/B scripts that flip a kernel choice mid-process).  Not for concurrent use with
+ * launches on other threads. */
+void gnlp_reload_knobs(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Masks.  Integer/byte work: results are bit-exact with the reference.

@@ -52,3 +52,61 @@ def test_batch_sharded_allgather_world2(B):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, B, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---- bench.py --gpus N means N (the flag used to be parsed and ignored) --------------
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_bench_resolve_launch_argument_logic():
+    b = _bench()
+    assert b.resolve_launch(1, {}, 0) == ('rank', 1)
+    assert b.resolve_launch(1, {'WORLD_SIZE': '1'}, 1) == ('rank', 1)
+    assert b.resolve_launch(4, {'WORLD_SIZE': '4'}, 8) == ('rank', 4)
+    assert b.resolve_launch(8, {}, 8) == ('spawn', 8)
+    with pytest.raises(SystemExit) as e:       # launcher and flag disagree
+        b.resolve_launch(8, {'WORLD_SIZE': '1'}, 8)
+    assert 'WORLD_SIZE=1' in str(e.value)
+    with pytest.raises(SystemExit) as e:       # 1-GPU box asked for 2: loud, never n_gpus = 1
+        b.resolve_launch(2, {}, 1)
+    assert 'only 1 GPU' in str(e.value)
+    with pytest.raises(SystemExit):
+        b.resolve_launch(0, {}, 1)
+
+
+def test_bench_gpus_2_without_gpus_fails_loudly():
+    """`python bench.py --gpus 2` on a box with fewer than 2 GPUs exits non-zero with a message and
+    prints no JSON line (this container has none; a 1-GPU box takes the same branch)."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps',
+                        '1', '--warmup', '0'], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0
+    assert 'GPU(s) are visible' in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
+
+
+def _count_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ret[rank] = _bench().count_ranks(dist, torch.device('cpu'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_count_ranks_world2():
+    world = 2
+    port = 29850 + (os.getpid() % 100)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_count_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 2, 1: 2}

@@ -8,11 +8,13 @@ size-independent properties plus a direct comparison of a few whole sequences:
   * permuting the sequences of the batch permutes the output rows BIT FOR BIT (every row is
     computed with the same K order whatever tile / workgroup it lands in);
   * padded positions are exactly zero where the reference applies sequence_mask (BERT / ELECTRA).
-Tolerances: bf16 2e-2, fp32 1e-5 (max |delta| / max |ref|, tests/util.py) PER LAYER, as SURVEY 8d
-states them ("within 1e-5 rel of the float64 oracle per layer"): every layer of the full-size stack
-is checked by feeding the oracle layer the device's own previous output (so rounding does not
-accumulate in the comparison), and the end-to-end output against the oracle run at full depth
-within sqrt(layers) x that tolerance (independent per-layer errors add in quadrature at worst)."""
+Tolerances: bf16 2e-2, fp32 1e-5 (global AND element-wise, tests/util.py rel_err) PER LAYER, as
+SURVEY 8d states them ("within 1e-5 rel of the float64 oracle per layer"): every layer of the
+full-size stack is checked by feeding the oracle layer the device's own previous output (so
+rounding does not accumulate in the comparison).  End to end against the oracle run at full depth:
+fp32 at the SAME 1e-5 (no allowance); bf16 within sqrt(layers) x 2e-2 -- 24 bf16 hand-offs between
+layers each round to 8 bits, measured 2.3e-2 at 24 layers, over the per-layer figure, and stated
+as such in DESIGN.md section 4.  Every measured end-to-end error is printed (pytest -s / -rP)."""
 import numpy as np
 import pytest
 import torch
@@ -38,7 +40,7 @@ def _ragged(rng, B, L):
     return vl
 
 
-def _stack_case(kind, dtype, U, F, H, NL, B, L, eps, seed, pick):
+def _stack_case(kind, dtype, U, F, H, NL, B, L, eps, seed, pick, vl=None):
     from gluonnlp_amd.models import BertTransformer, ElectraEncoder, RobertaEncoder
     rng = np.random.default_rng(seed)
     cls = {'bert': BertTransformer, 'electra': ElectraEncoder, 'roberta': RobertaEncoder}[kind]
@@ -51,7 +53,7 @@ def _stack_case(kind, dtype, U, F, H, NL, B, L, eps, seed, pick):
         load_params(layer, lp, dtype)
     m.cuda()
     x = rng.standard_normal((B, L, U)).astype(np.float32)
-    vl = _ragged(rng, B, L)
+    vl = _ragged(rng, B, L) if vl is None else np.asarray(vl)
     xd = to_dev(x, dtype)
     vld = torch.from_numpy(vl).cuda()
     outs, _ = m(xd, vld)
@@ -67,19 +69,30 @@ def _stack_case(kind, dtype, U, F, H, NL, B, L, eps, seed, pick):
     # (1a) every layer at full size: oracle layer on the device's own previous output
     mask = ref.gen_self_attn_mask((len(pick), L), vl[pick])
     prev = prep(x[pick], dtype)
+    worst_layer = 0.0
     for i in range(NL):
         want_i, _ = ref.transformer_encoder_layer(prev, mask, olps[i], H, eps, False, 'gelu')
         got_i = to_np(outs[i][torch.tensor(pick, device='cuda')])
         for j, b in enumerate(pick):
             n = vl[b]
-            assert rel_err(got_i[j, :n], want_i[j, :n]) < t, (kind, 'layer', i, 'seq', b)
+            e = rel_err(got_i[j, :n], want_i[j, :n])
+            worst_layer = max(worst_layer, float(e))
+            assert e < t, (kind, 'layer', i, 'seq', b)
         prev = got_i
-    # (1b) whole sequences against the oracle at full depth and full L
+    # (1b) whole sequences against the oracle at full depth and full L: fp32 at the per-layer
+    # tolerance itself; bf16 with the sqrt(layers) allowance for the NL roundings between layers
     enc = ref.roberta_encoder if kind == 'roberta' else ref.bert_transformer
     want, _ = enc(prep(x[pick], dtype), vl[pick], olps, H, eps, 'gelu')
+    t_e2e = t if dtype == torch.float32 else t * NL ** 0.5
+    worst_e2e = 0.0
     for j, b in enumerate(pick):
         n = vl[b]
-        assert rel_err(got[b, :n], want[j, :n]) < t * NL ** 0.5, (kind, b, n)
+        e = rel_err(got[b, :n], want[j, :n])
+        worst_e2e = max(worst_e2e, float(e))
+        assert e < t_e2e, (kind, b, n)
+    print('[fullsize] {} {} U={} L={} B={} layers={}: worst per-layer err {:.3e} (tol {:.0e}), '
+          'end-to-end err {:.3e} (tol {:.2e})'.format(kind, str(dtype).split('.')[-1], U, L, B, NL,
+                                                      worst_layer, t, worst_e2e, t_e2e))
     # (2) permutation of the batch = permutation of the rows, bit for bit
     perm = torch.from_numpy(rng.permutation(B)).cuda()
     outs_p, _ = m(xd[perm].contiguous(), vld[perm].contiguous())
@@ -89,6 +102,16 @@ def _stack_case(kind, dtype, U, F, H, NL, B, L, eps, seed, pick):
         keep = torch.arange(L, device='cuda')[None, :] < vld[:, None]
         assert (out[~keep] == 0).all()
     return got
+
+
+@pytest.mark.parametrize('lengths', ['full', 'ragged'])
+def test_cfg1_bert_base_fp32_full_size(nlp, lengths):
+    """Config 1 (BASELINE.json configs[0]): BERT-base fp32, B=8, L=128, the WHOLE
+    batch against the float64 oracle, valid_length full (as the reference harness runs it) and
+    default_rng(0).integers(1, L+1); 1e-5 per layer and end to end, no allowance."""
+    B, L = 8, 128
+    vl = np.full(B, L) if lengths == 'full' else np.random.default_rng(0).integers(1, L + 1, B)
+    _stack_case('bert', torch.float32, 768, 3072, 12, 12, B, L, 1e-12, 300, list(range(B)), vl=vl)
 
 
 def test_cfg3_bert_large_full_size(nlp):
@@ -142,9 +165,14 @@ def test_cfg4_t5_base_full_size(nlp):
     want = ref.t5_encoder(o(x[pick]), vl[pick], o(relw),
                           [{k: o(v) for k, v in p.items()} for p in lps],
                           {k: o(v) for k, v in fin.items()}, H, activation_name='relu')
+    worst = 0.0
     for j, b in enumerate(pick):
         n = vl[b]
-        assert rel_err(got[b, :n], want[j, :n]) < tol(dtype) * NL ** 0.5, (b, n)
+        e = rel_err(got[b, :n], want[j, :n])
+        worst = max(worst, float(e))
+        assert e < tol(dtype) * NL ** 0.5, (b, n)
+    print('[fullsize] t5_base bf16 L=1024 B=16 layers=12: end-to-end err {:.3e} (tol {:.2e})'
+          .format(worst, tol(dtype) * NL ** 0.5))
     perm = torch.from_numpy(rng.permutation(B)).cuda()
     out_p = enc(xd[perm].contiguous(), vld[perm].contiguous())
     keep = (torch.arange(L, device='cuda')[None, :] < vld[:, None])[perm]

@@ -304,20 +304,29 @@ def test_dense_persistent(nlp, M, N, K, monkeypatch):
             ref.activation(base, 'gelu(tanh)') * oo, ref.dense(xo, wo), ref.dense(xo, wo) + oo]
     for g, e in zip(got, want):
         assert rel_err(to_np(g), e) < t
-    monkeypatch.setenv('GNLP_GEMM_PS', '0')
-    for g, h in zip(got, variants()):
-        assert torch.equal(g, h)
-    # a second call on the same buffers gives the same bits (no state left in LDS / scratch)
-    monkeypatch.delenv('GNLP_GEMM_PS')
-    for g, h in zip(got, variants()):
-        assert torch.equal(g, h)
-    # the three 256x256x64 kernels (one wave per SIMD, gemm_bf16_w4.hip, the default; 8 waves
-    # persistent, gemm_bf16_ps.hip; one tile per workgroup, gemm_bf16_pp.hip) accumulate in the
-    # same order with the same fp32 epilogue: bit for bit equal
-    monkeypatch.setenv('GNLP_GEMM_W4', '0')
-    for g, h in zip(got, variants()):
-        assert torch.equal(g, h)
-    monkeypatch.delenv('GNLP_GEMM_W4')
+    from gluonnlp_amd import _lib
+    reload_knobs = _lib.load().gnlp_reload_knobs   # the knobs are read once per process
+    try:
+        monkeypatch.setenv('GNLP_GEMM_PS', '0')
+        reload_knobs()
+        for g, h in zip(got, variants()):
+            assert torch.equal(g, h)
+        # a second call on the same buffers gives the same bits (no state left in LDS / scratch)
+        monkeypatch.delenv('GNLP_GEMM_PS')
+        reload_knobs()
+        for g, h in zip(got, variants()):
+            assert torch.equal(g, h)
+        # the three 256x256x64 kernels (one wave per SIMD, gemm_bf16_w4.hip, the default; 8 waves
+        # persistent, gemm_bf16_ps.hip; one tile per workgroup, gemm_bf16_pp.hip) accumulate in
+        # the same order with the same fp32 epilogue: bit for bit equal
+        monkeypatch.setenv('GNLP_GEMM_W4', '0')
+        reload_knobs()
+        for g, h in zip(got, variants()):
+            assert torch.equal(g, h)
+    finally:
+        monkeypatch.delenv('GNLP_GEMM_W4', raising=False)
+        monkeypatch.delenv('GNLP_GEMM_PS', raising=False)
+        reload_knobs()
 
 
 def test_dense_mfma_layout_asymmetric(nlp):

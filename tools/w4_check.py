@@ -17,7 +17,7 @@ def one(M, N, K, act, other):
     o = torch.randn(M, N, device='cuda').to(torch.bfloat16) if other else None
     outs = []
     for v in ('0', '1'):
-        os.environ['GNLP_GEMM_W4'] = v
+        __import__('gluonnlp_amd._lib', fromlist=['x']).set_knob('GNLP_GEMM_W4', v)
         out = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
         d(x, act=act, other=o, out=out)
         torch.cuda.synchronize()
@@ -47,7 +47,7 @@ if __name__ == '__main__':
     if ok and os.environ.get('BENCH', '1') == '1':
         from gemm_bench import run
         for v in ('0', '1', '0', '1'):
-            os.environ['GNLP_GEMM_W4'] = v
+            __import__('gluonnlp_amd._lib', fromlist=['x']).set_knob('GNLP_GEMM_W4', v)
             line = []
             for name, m, n, k, act, other in [('qkv', 32768, 3072, 1024, 'identity', False),
                                               ('proj', 32768, 1024, 1024, 'identity', True),

@@ -12,7 +12,7 @@ x = torch.randn(M, K, device='cuda').to(torch.bfloat16)
 o = torch.randn(M, N, device='cuda').to(torch.bfloat16)
 out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
 for w4 in ('0', '1'):
-    os.environ['GNLP_GEMM_W4'] = w4
+    __import__('gluonnlp_amd._lib', fromlist=['x']).set_knob('GNLP_GEMM_W4', w4)
     for _ in range(25):
         d(x, other=o, out=out)
     torch.cuda.synchronize()
