@@ -44,7 +44,6 @@ void reload_knobs() {
   k.gemm_w4 = env_on("GNLP_GEMM_W4");
   const int nt = env_int("GNLP_GEMM_NT", 0, 0, 256);
   k.gemm_nt = (nt == 192 || nt == 256) ? nt : 0;
-  k.gemm_krev = env_on("GNLP_GEMM_KREV");
   k.norm_nt = env_on("GNLP_NORM_NT");
   const char *mv = getenv("GNLP_NORM_MAXV");
   k.norm_full = mv && mv[0] == 'f';
@@ -60,6 +59,7 @@ const Knobs &knobs() {
 namespace {
 
 thread_local std::string g_err;
+thread_local int g_attn_kernel = 0;   // which kernel the last attention dispatch on this thread took
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -182,6 +182,8 @@ int dense_launch(void *out, const void *x, const void *w, const void *bias, cons
 size_t attn_ws_bytes(const gnlp_attn_desc *d, int dtype, bool want_scores, bool want_weights,
                      bool fused) {
   if (fused) return 0;
+  if (d->dk <= 128 && d->dv <= 128 && ((d->Lq + 31) / 32) * d->H * d->B <= 0x7fffffffLL)
+    return 0;   // attn_gen.hip (gen_attn_supported): nothing is materialised
   if (want_scores && want_weights) return 0;
   return align256((size_t)d->B * d->H * d->Lq * d->Lm * esize(dtype));
 }
@@ -216,8 +218,32 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     if (edge) for (int i = 0; i < 4; ++i) fa.bs[i] = es[i];
     fa.inv_temperature = inv_t;
     launch_fused_attn_bf16(fa, s);
+    g_attn_kernel = GNLP_ATTN_KERNEL_FUSED_BF16;
     return check_launch("fused attention");
   }
+  {   // ---- general MFMA kernel: fp32, other head dims, scores / weights wanted; no workspace ----
+    GenAttn ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.q = q; ga.k = k; ga.v = v; ga.o = ctx;
+    ga.scores_out = scores_out; ga.weights_out = weights_out;
+    ga.B = d->B; ga.H = d->H; ga.Lq = d->Lq; ga.Lm = d->Lm; ga.dk = d->dk; ga.dv = d->dv;
+    for (int i = 0; i < 3; ++i) {
+      ga.qs[i] = d->q_stride[i]; ga.ks[i] = d->k_stride[i];
+      ga.vs[i] = d->v_stride[i]; ga.os[i] = d->o_stride[i];
+    }
+    ga.mask = mask;
+    if (mask) { ga.ms[0] = ms[0]; ga.ms[1] = ms[1]; ga.ms[2] = ms[2]; }
+    ga.vl = vl; ga.vl_dtype = vl_dtype;
+    ga.bias = edge;
+    if (edge) for (int i = 0; i < 4; ++i) ga.bs[i] = es[i];
+    ga.inv_temperature = inv_t;
+    if (gen_attn_supported(ga)) {   // (Lm = 0 falls through: K = 0 GEMMs write the zeros)
+      launch_gen_attn(ga, dtype, s);
+      g_attn_kernel = GNLP_ATTN_KERNEL_GENERAL_MFMA;
+      return check_launch("general attention");
+    }
+  }
+  g_attn_kernel = GNLP_ATTN_KERNEL_UNFUSED;
   // ---- unfused path: scores -> masked softmax -> context (attention_cell.py:452-463) ----
   const size_t need = attn_ws_bytes(d, dtype, scores_out != nullptr, weights_out != nullptr, false);
   REQUIRE(ws_bytes >= need && (need == 0 || ws != nullptr),
@@ -425,6 +451,7 @@ int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
 extern "C" {
 
 int gnlp_version(void) { return 200; }
+int gnlp_attn_last_kernel(void) { return g_attn_kernel; }
 void gnlp_reload_knobs(void) { reload_knobs(); }
 const char *gnlp_last_error(void) { return g_err.c_str(); }
 int gnlp_device_count(void) {

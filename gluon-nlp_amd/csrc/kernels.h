@@ -35,7 +35,6 @@ struct Knobs {
   bool gemm_ps;     // GNLP_GEMM_PS=0: one tile per workgroup instead of the persistent kernels
   bool gemm_w4;     // GNLP_GEMM_W4=0: the 8-wave persistent kernel instead of one wave per SIMD
   int gemm_nt;      // GNLP_GEMM_NT: 0 = by shape, 192 / 256 forced tile width
-  bool gemm_krev;   // GNLP_GEMM_KREV=0: every tile walks K forwards (see gemm_bf16_w4.hip)
   bool norm_nt;     // GNLP_NORM_NT=0: plain instead of non-temporal loads in the norm kernel
   bool norm_full;   // GNLP_NORM_MAXV=f: always the full-width register image
 };
@@ -172,5 +171,24 @@ struct FusedAttn {
 };
 bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv);
 void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s);
+
+// attn_gen.hip : general attention on the f32 matrix cores (float32 or bf16 tensors, head dims
+// <= 128, optional `scores` / `attn_weights` outputs); no workspace
+struct GenAttn {
+  const void *q, *k, *v;
+  void *o;
+  void *scores_out, *weights_out;       // (B, H, Lq, Lm) contiguous, or null
+  int64_t B, H, Lq, Lm, dk, dv;
+  int64_t qs[3], ks[3], vs[3], os[3];   // (b, h, t) element strides
+  const uint8_t *mask;                  // or null
+  int64_t ms[3];                        // (b, i, j)
+  const void *vl;                       // or null (predicate i<vl && j<vl, used when mask is null)
+  int vl_dtype;
+  const void *bias;                     // edge scores (tensor dtype) or null
+  int64_t bs[4];                        // (b, h, i, j)
+  float inv_temperature;
+};
+bool gen_attn_supported(const GenAttn &a);
+void launch_gen_attn(const GenAttn &a, int dtype, hipStream_t s);
 
 }  // namespace gnlp

@@ -20,6 +20,7 @@ ACT = {None: 0, 'identity': 0, 'relu': 1, 'gelu': 2, 'gelu(tanh)': 3, 'gelu(sigm
        'sigmoid': 5, 'tanh': 6, 'leaky': 7, 'elu': 8, 'softrelu': 9, 'softsign': 10}
 NORM = {'layer_norm': 0, 'rms_norm': 1, 'no_norm': 2}
 COMBINE_ADD, COMBINE_MUL = 0, 1
+ATTN_KERNEL_NONE, ATTN_KERNEL_FUSED_BF16, ATTN_KERNEL_GENERAL_MFMA, ATTN_KERNEL_UNFUSED = 0, 1, 2, 3
 
 
 class AttnDesc(Structure):
@@ -70,6 +71,7 @@ PROTOTYPES = {
     'gnlp_last_error': (c_char_p, []),
     'gnlp_device_count': (c_int, []),
     'gnlp_reload_knobs': (None, []),
+    'gnlp_attn_last_kernel': (c_int, []),
     'gnlp_gen_self_attn_mask': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int,
                                         c_void_p]),
     'gnlp_gen_mem_attn_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,

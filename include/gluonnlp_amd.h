@@ -157,11 +157,12 @@ int gnlp_dense(void *out, const void *x, const void *w, const void *bias, const 
  * temperature: sqrt(query_head_units) when scaled, 0 / 1 otherwise.
  * scores_out / weights_out: (B, H, Lq, Lm) contiguous or NULL; scores_out = QK^T + edge_scores
  *   (not divided by the temperature), weights_out = the softmax (attention_cell.py:524).
- * When both are NULL and the shape allows it (bf16, dk = dv = 64) the fused MFMA kernel runs and
- * the (B, H, Lq, Lm) tensor is never formed.  l2-normalisation (normalized=True) is done by the
- * caller with gnlp_l2_normalize.
- * workspace: only needed by the unfused path when scores_out or weights_out is NULL
- *   (gnlp_attn_workspace_bytes); may be NULL otherwise.
+ * When both are NULL and the shape allows it (bf16, dk = dv = 64) the fused bf16 MFMA kernel runs;
+ * every other call with head dims <= 128 (float32, dk = 8 / dv = 6, scores or weights wanted) runs
+ * the general kernel on the f32 matrix cores.  Neither forms (B, H, Lq, Lm) beyond the outputs
+ * asked for.  l2-normalisation (normalized=True) is done by the caller with gnlp_l2_normalize.
+ * workspace: only needed for head dims > 128 (strided GEMM + softmax + GEMM) when scores_out or
+ *   weights_out is NULL (gnlp_attn_workspace_bytes); may be NULL otherwise.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int64_t B, H, Lq, Lm, dk, dv;
@@ -170,6 +171,15 @@ typedef struct {
 
 size_t gnlp_attn_workspace_bytes(const gnlp_attn_desc *d, int dtype, int want_scores,
                                  int want_weights);
+
+/* Which kernel the last gnlp_multi_head_dot_attn / block call on THIS thread dispatched its
+ * attention to (diagnostics and tests; no counterpart in the reference):
+ * FUSED_BF16 = attn_bf16.hip (bf16, dk = dv = 64, nothing but ctx wanted), GENERAL_MFMA =
+ * attn_gen.hip (float32 or bf16, head dims <= 128, optional scores / weights, on the f32 matrix
+ * cores), UNFUSED = strided GEMM + softmax + GEMM on the vector ALU (head dims > 128 only). */
+enum { GNLP_ATTN_KERNEL_NONE = 0, GNLP_ATTN_KERNEL_FUSED_BF16 = 1,
+       GNLP_ATTN_KERNEL_GENERAL_MFMA = 2, GNLP_ATTN_KERNEL_UNFUSED = 3 };
+int gnlp_attn_last_kernel(void);
 
 int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, const void *q,
                              const void *k, const void *v, const gnlp_attn_desc *d, int dtype,

@@ -13,6 +13,8 @@ from tests.util import (load_params, oracle_params, prep, rel_err, to_dev, to_np
 
 pytestmark = pytest.mark.gpu
 
+from gluonnlp_amd import _lib  # noqa: E402
+
 G = os.path.join(os.path.dirname(__file__), 'golden')
 DT = {torch.float32: 'float32', torch.bfloat16: 'bfloat16'}
 
@@ -59,6 +61,8 @@ def test_attention_goldens(nlp, H, dtype):
                                                  layout=layout)
                 ctx, (scores, w) = cell(qq, kk, vv, torch.tensor(mask, device='cuda'),
                                         None if e is None else to_dev(e, dtype))
+                # d_k = 8 / d_v = 6, float32 and bf16: the MFMA kernel, not the VALU path
+                assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_GENERAL_MFMA
                 ctx = to_np(ctx)
                 if back is not None:
                     ctx = np.transpose(ctx, back)
@@ -131,6 +135,7 @@ def test_fused_attention_bf16_d64(nlp, layout, mode, Lq, Lm):
     ctx, (s_, w_) = ac.multi_head_dot_attn(qq, kk, vv, mask, ed, query_head_units=d, layout=layout,
                                            _need_scores=False, _need_weights=False)
     assert s_ is None and w_ is None
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_FUSED_BF16
     ectx, _ = ref.multi_head_dot_attn(prep(q, torch.bfloat16), prep(k, torch.bfloat16),
                                       prep(v, torch.bfloat16), mask_np,
                                       None if e is None else prep(e, torch.bfloat16),
@@ -147,8 +152,31 @@ def test_fused_attention_bf16_d64(nlp, layout, mode, Lq, Lm):
     got2 = to_np(ctx2)
     if layout == 'TNK':
         got2 = np.transpose(got2, (1, 0, 2))
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_GENERAL_MFMA
     assert rel_err(got2, ectx) < 2e-2
     assert s2 is not None and w2 is not None
+    _, (es, ew) = ref.multi_head_dot_attn(prep(q, torch.bfloat16), prep(k, torch.bfloat16),
+                                          prep(v, torch.bfloat16), mask_np,
+                                          None if e is None else prep(e, torch.bfloat16),
+                                          query_head_units=d)
+    assert rel_err(to_np(s2), es) < 2e-2 and rel_err(to_np(w2), ew) < 2e-2
+    # the same tensors in float32 through the same kernel, at the fp32 tolerance
+    q3, k3, v3 = [t_.float() for t_ in (qq, kk, vv)]
+    ctx3, (s3, w3) = ac.multi_head_dot_attn(q3, k3, v3, mask, None if ed is None else ed.float(),
+                                            query_head_units=d, layout=layout)
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_GENERAL_MFMA
+    got3 = to_np(ctx3)
+    if layout == 'TNK':
+        got3 = np.transpose(got3, (1, 0, 2))
+    assert rel_err(got3, ectx) < 1e-5
+    assert rel_err(to_np(s3), es) < 1e-5 and rel_err(to_np(w3), ew) < 1e-5
+    ctx4, _ = ac.multi_head_dot_attn(q3, k3, v3, mask, None if ed is None else ed.float(),
+                                     query_head_units=d, layout=layout, _need_scores=False,
+                                     _need_weights=False)       # one-pass form
+    got4 = to_np(ctx4)
+    if layout == 'TNK':
+        got4 = np.transpose(got4, (1, 0, 2))
+    assert rel_err(got4, ectx) < 1e-5
 
 
 def test_fused_attention_from_packed_qkv(nlp):

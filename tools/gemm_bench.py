@@ -33,7 +33,8 @@ if __name__ == '__main__':
     for rnd in range(int(os.environ.get('ROUNDS', 2))):
         for v in vals:
             if knob:
-                os.environ[knob] = v
+                from gluonnlp_amd import _lib
+                _lib.set_knob(knob, v)
             tot = 0
             line = []
             for name, m, n, k, act, other in shapes:
