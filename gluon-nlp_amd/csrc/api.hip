@@ -436,6 +436,31 @@ int encoder_layer_impl(void *out, const void *x, const gnlp_encoder_layer_params
                   c->time_major, base + w.ffn, w.total - w.ffn, s);  // :271
 }
 
+// ---- static scratch of gnlp_encoder_layer_forward_noalloc ----------------------------------------
+// A file-scope device array: every GPU the library runs on holds its own copy until the process
+// ends.  Its NAME is a host-side stand-in, not a device address: the address of a device's copy is
+// looked up once per device with hipGetSymbolAddress (that device current) and only that pointer
+// is ever handed to kernels.
+constexpr size_t kStaticScratchBytes = GNLP_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+std::atomic<void *> g_scratch_ptr[64];   // per device ordinal
+
+int static_scratch(void **ptr) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(GNLP_ERR_LAUNCH, "hipGetDevice failed");
+  if (dev < 0 || dev >= 64) return fail(GNLP_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
+  void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p)
+      return fail(GNLP_ERR_LAUNCH, "hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                  hipGetErrorString(e));
+    g_scratch_ptr[dev].store(p, std::memory_order_release);   // (a racing thread stores the same)
+  }
+  *ptr = p;
+  return GNLP_OK;
+}
+
 int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
   REQUIRE(c != nullptr, "cfg is NULL");
   REQUIRE(dtype_ok(c->dtype), "unsupported dtype %d", c->dtype);
@@ -744,6 +769,33 @@ int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_laye
   REQUIRE(out && x && out != x, "NULL or aliased tensors");
   return encoder_layer_impl(out, x, p, cfg, B, L, mask, valid_length, vl_dtype, attn_weights_out,
                             final_seq_mask, workspace, workspace_bytes, S(stream));
+}
+
+int gnlp_encoder_layer_forward_noalloc(void *out, const void *x,
+                                       const gnlp_encoder_layer_params *p,
+                                       const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                                       const uint8_t *mask, const void *valid_length,
+                                       int vl_dtype, void *attn_weights_out, int final_seq_mask,
+                                       gnlp_stream_t stream) {
+  int rc = check_encoder_cfg(cfg, B, L);
+  if (rc) return rc;
+  REQUIRE(p && p->qkv_w && p->proj_w && p->ln_g && p->ffn.ffn1_w && p->ffn.ffn2_w && p->ffn.ln_g,
+          "missing layer weights");
+  if (B * L == 0) return GNLP_OK;
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype");
+  REQUIRE(!final_seq_mask || valid_length, "final_seq_mask needs valid_length");
+  REQUIRE(out && x && out != x, "NULL or aliased tensors");
+  const size_t need = enc_ws(cfg, B, L, attn_weights_out != nullptr).total;
+  REQUIRE(need <= kStaticScratchBytes,
+          "gnlp_encoder_layer_forward_noalloc: this layer needs %zu bytes of scratch, the static "
+          "scratch holds %zu (GNLP_NOALLOC_SCRATCH_BYTES); use gnlp_encoder_layer_forward with a "
+          "caller-owned workspace", need, kStaticScratchBytes);
+  void *ws = nullptr;
+  rc = static_scratch(&ws);   // first call on this device: one hipGetSymbolAddress, no allocation
+  if (rc) return rc;
+  // every region of the scratch is written by this call before it is read: nothing to clear
+  return encoder_layer_impl(out, x, p, cfg, B, L, mask, valid_length, vl_dtype, attn_weights_out,
+                            final_seq_mask, ws, kStaticScratchBytes, S(stream));
 }
 
 int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_layer_params *layers,

@@ -20,6 +20,7 @@ ACT = {None: 0, 'identity': 0, 'relu': 1, 'gelu': 2, 'gelu(tanh)': 3, 'gelu(sigm
        'sigmoid': 5, 'tanh': 6, 'leaky': 7, 'elu': 8, 'softrelu': 9, 'softsign': 10}
 NORM = {'layer_norm': 0, 'rms_norm': 1, 'no_norm': 2}
 COMBINE_ADD, COMBINE_MUL = 0, 1
+NOALLOC_SCRATCH_BYTES = 64 << 20
 ATTN_KERNEL_NONE, ATTN_KERNEL_FUSED_BF16, ATTN_KERNEL_GENERAL_MFMA, ATTN_KERNEL_UNFUSED = 0, 1, 2, 3
 
 
@@ -121,6 +122,10 @@ PROTOTYPES = {
                                            POINTER(EncoderCfg), c_int64, c_int64, c_void_p,
                                            c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,
                                            c_void_p]),
+    'gnlp_encoder_layer_forward_noalloc': (c_int, [c_void_p, c_void_p,
+                                                   POINTER(EncoderLayerParams),
+                                                   POINTER(EncoderCfg), c_int64, c_int64, c_void_p,
+                                                   c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'gnlp_encoder_stack_forward': (c_int, [c_void_p, c_void_p, POINTER(EncoderLayerParams), c_int,
                                            POINTER(EncoderCfg), c_int64, c_int64, c_void_p, c_int,
                                            c_int, POINTER(c_void_p), c_void_p, c_size_t,

@@ -286,6 +286,27 @@ int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_laye
                                void *attn_weights_out, int final_seq_mask, void *workspace,
                                size_t workspace_bytes, gnlp_stream_t stream);
 
+/* gnlp_encoder_layer_forward for callers that CANNOT allocate device memory or size a workspace:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments and results (bit for bit: the same kernels) as
+ * gnlp_encoder_layer_forward minus the workspace: the layer's scratch (packed QKV, context,
+ * pre-norm sums, FFN hidden) lives in a static device array of GNLP_NOALLOC_SCRATCH_BYTES inside
+ * the library -- every GPU the library runs on holds one copy until the process ends.  The call
+ * performs no hipMalloc / hipFree and calls no allocating routine; on its first use on a device it
+ * looks the array's address up once (hipGetSymbolAddress).  A layer whose scratch
+ * (gnlp_encoder_workspace_bytes minus the stack's two ping-pong activations) exceeds the array is
+ * refused with GNLP_ERR_ARG and a message.  Every call on a GPU shares that GPU's array: calls that
+ * overlap in time on one GPU (different streams or threads) RACE -- serialise them, or use the
+ * workspace form.  Nothing in the array has to start at zero (each call writes every region
+ * before reading it), so the previous call's contents are harmless. */
+#define GNLP_NOALLOC_SCRATCH_BYTES ((size_t)64 << 20)
+int gnlp_encoder_layer_forward_noalloc(void *out, const void *x,
+                                       const gnlp_encoder_layer_params *p,
+                                       const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                                       const uint8_t *mask, const void *valid_length,
+                                       int vl_dtype, void *attn_weights_out, int final_seq_mask,
+                                       gnlp_stream_t stream);
+
 /* BertTransformer / RobertaEncoder / ElectraEncoder / TransformerEncoder (post-norm) .forward
  * models/bert.py:259-315, roberta.py:171-188, electra.py:249-307, transformer.py:346-385.
  * Runs n_layers layers back to back; mask is the valid_length predicate.
