@@ -49,6 +49,21 @@
 
 namespace gnlp {
 
+#ifdef W4_STAMP   // diagnostic build only (tools/w4_stamp.py): where a K-tile's cycles go
+__device__ unsigned w4_dbg[256 * 4 * 16];
+#define W4_STAMP_AT(k)                                                      \
+  do {                                                                      \
+    W4_SB();                                                                \
+    const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();           \
+    if ((k) == 0) { if (st_v) { st_d[7] += now_ - st_last; ++st_n7; } st_v = 1; ++st_n; } \
+    else st_d[(k) - 1] += now_ - st_last;                                   \
+    st_last = now_;                                                         \
+    W4_SB();                                                                \
+  } while (0)
+#else
+#define W4_STAMP_AT(k) do {} while (0)
+#endif
+
 struct DenseW4Args {
   const bf16 *x, *w, *bias, *other;
   bf16 *out;
@@ -97,6 +112,11 @@ template <> struct W4Slots<6> {   // 96 MFMAs, k-step 1 from t = 48, 6 weight pi
   static constexpr int BAR3 = 70;
   static constexpr int R0[14] = {71, 72, 74, 75, 77, 78, 79, 80, 81, 82, 84, 86, 88, 90};
 };
+constexpr int w4_count_le(const int *tab, int n, int t) {
+  int c = 0;
+  for (int q = 0; q < n; ++q) c += tab[q] <= t ? 1 : 0;
+  return c;
+}
 constexpr int w4_find(const int *tab, int n, int t) {
   for (int q = 0; q < n; ++q)
     if (tab[q] == t) return q;
@@ -201,9 +221,18 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   // ---- one K-tile: 128 MFMAs with the memory instructions in between (see the header) ----
   // FIRST: the tile's first K-tile starts the accumulators from the inline constant 0 (no
   // zeroing pass over 256 registers per tile).
+#ifdef W4_STAMP
+  unsigned st_d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_n = 0, st_n7 = 0, st_v = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   auto ktile = [&](auto firstc, char *X, char *Y, const bf16 *pA,
                    const bf16 *pB) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
+    if constexpr (!FIRST) W4_STAMP_AT(0);
+#ifdef W4_STAMP
+    if constexpr (FIRST) st_v = 0;   // the K-tile after a drain is not a steady-state one
+#endif
     w4_static_for<16 * NJ>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
       constexpr int s = t / (8 * NJ), j = (t % (8 * NJ)) >> 3, i = t & 7;
@@ -224,17 +253,25 @@ dense_bf16_w4_kernel(DenseW4Args a) {
                     r0 = w4_find(S::R0, 8 + NJ, t);
       if constexpr (ra1 >= 0) rd_a(X, 1, ra1);
       if constexpr (t == S::BAR1 - 1) { W4_SB(); W4_LGKM0(); }
+      if constexpr (t == S::BAR1 && !FIRST) W4_STAMP_AT(1);
       if constexpr (t == S::BAR1) W4_BAR();
+      if constexpr (t == S::BAR1 && !FIRST) W4_STAMP_AT(2);
       if constexpr (ia >= 0) stage_a(X, pA, ia);
       if constexpr (rb1 >= 0) rd_b(X, 1, rb1);
       if constexpr (t == S::BAR2 - 1) { W4_SB(); W4_LGKM0(); }
+      if constexpr (t == S::BAR2 && !FIRST) W4_STAMP_AT(3);
       if constexpr (t == S::BAR2) W4_BAR();
+      if constexpr (t == S::BAR2 && !FIRST) W4_STAMP_AT(4);
       if constexpr (ib >= 0) stage_b(X, pB, ib);
       if constexpr (t == S::BAR3 - 1) {   // the requests of THIS K-tile issued so far may fly on
+        constexpr int NFLY = w4_count_le(S::SA, 8, t) + w4_count_le(S::SB, NJ, t);
+        if constexpr (!FIRST) W4_STAMP_AT(5);
         W4_SB();
-        asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // 8 A + 3 B pieces, either width
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFLY) : "memory");
+        if constexpr (!FIRST) W4_STAMP_AT(6);
       }
-      if constexpr (t == S::BAR3) W4_BAR();
+      if constexpr (t == S::BAR3 && S::BAR3 != S::BAR2) W4_BAR();
+      if constexpr (t == S::BAR3 && !FIRST) W4_STAMP_AT(7);
       if constexpr (r0 >= 0 && r0 < 8) rd_a(Y, 0, r0);
       if constexpr (r0 >= 8) rd_b(Y, 0, r0 - 8);
       W4_SB();
@@ -440,6 +477,15 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     drain(m0, n0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two requests past the end
+#ifdef W4_STAMP
+  if (lane == 0 && blockIdx.x < 256) {
+    unsigned *d = w4_dbg + (blockIdx.x * 4 + wave) * 16;
+    for (int k = 0; k < 8; ++k) d[k] = st_d[k];
+    d[8] = st_n; d[9] = st_n7;
+    d[10] = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0);       // shader cycles
+    d[11] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);   // 100 MHz ticks
+  }
+#endif
 #endif
 }
 
@@ -528,3 +574,9 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
 }
 
 }  // namespace gnlp
+
+#ifdef W4_STAMP
+extern "C" int gnlp_debug_w4_read(unsigned *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gnlp::w4_dbg), (size_t)n * sizeof(unsigned));
+}
+#endif
