@@ -325,3 +325,36 @@ def test_parameter_files_round_trip(tmp_path):
     open(bad, 'wb').write(b'\x12\x01\x00\x00 not a parameter file')
     with pytest.raises(ValueError):
         read_parameter_file(bad)
+
+
+def test_reference_layout_parameter_fixture_loads_by_name():
+    """tests/golden/bert_hf_h4.params (oracle/gen_params_fixture.py): a parameter file in the
+    reference's on-disk layout -- MXNet 2.x save_parameters' npz container under a .params suffix,
+    float32, keyed by BertModel's structural names spelled out from the reference's class
+    definitions -- and the same arrays as a torch state_dict.  Both load into BertModel by name
+    with nothing missing and nothing extra, into float32 and bfloat16 models alike, and hold the
+    arrays of the HuggingFace golden they were made from (the GPU test checks the outputs)."""
+    import zipfile
+    from gluonnlp_amd.models import BertModel
+    from gluonnlp_amd.utils import load_parameters, read_parameter_file
+    G = os.path.join(ROOT, 'tests', 'golden')
+    g = np.load(os.path.join(G, 'bert_hf_h4.npz'))
+    want = {k[2:]: g[k].astype(np.float32) for k in g.files if k.startswith('p:')}
+    V, U = want['word_embed.weight'].shape
+    kw = dict(vocab_size=V, units=U, hidden_size=want['encoder.all_layers.0.ffn.ffn_1.weight'].shape[0],
+              num_layers=int(g['num_layers']), num_heads=int(g['num_heads']),
+              max_length=want['token_pos_embed._embed.weight'].shape[0])
+    f = os.path.join(G, 'bert_hf_h4.params')
+    with zipfile.ZipFile(f) as z:     # the container itself: .npy members, stored uncompressed
+        assert all(n.endswith('.npy') for n in z.namelist())
+        assert all(i.compress_type == zipfile.ZIP_STORED for i in z.infolist())
+    for path in (f, os.path.join(G, 'bert_hf_h4.state_dict.pt')):
+        loaded = read_parameter_file(path)
+        assert set(loaded) == set(want)
+        for dn, dt in (('float32', torch.float32), ('bfloat16', torch.bfloat16)):
+            m = load_parameters(BertModel(dtype=dn, **kw), path)    # strict: no missing, no extra
+            own = dict(m.named_parameters())
+            assert set(own) == set(want)
+            for k, v in want.items():
+                assert own[k].dtype == dt
+                assert torch.equal(own[k].data, torch.from_numpy(v).to(dt)), k

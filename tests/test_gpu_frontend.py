@@ -371,3 +371,40 @@ def test_bert_model_against_hf_goldens(nlp, name, layout, dtype):
         assert rel_err(seq_n[b, :vl[b]], want_seq[b, :vl[b]]) < t, b
         assert (seq_n[b, vl[b]:] == 0).all()
     assert rel_err(to_np(pooled), want_pooled) < t
+
+
+@pytest.mark.parametrize('suffix', ['.params', '.state_dict.pt'])
+def test_bert_model_from_reference_layout_parameter_file(nlp, suffix):
+    """a LOCAL parameter file in the reference's on-disk layout
+    (tests/golden/bert_hf_h4.params: MXNet 2.x save_parameters' npz container, float32, structural
+    names; and the torch state_dict form -- oracle/gen_params_fixture.py) is read by
+    utils.load_parameters into BertModel, and token ids -> (contextual embeddings, pooled output)
+    then match HuggingFace's outputs for those weights (fp32, 1e-5) and the oracle on
+    bf16-rounded parameters (bf16)."""
+    from gluonnlp_amd.models import BertModel
+    from gluonnlp_amd.utils import load_parameters
+    from tests.test_oracle_golden import bert_from_ids
+    g = np.load(os.path.join(G, 'bert_hf_h4.npz'))
+    p = {k[2:]: g[k] for k in g.files if k.startswith('p:')}
+    V, U = p['word_embed.weight'].shape
+    NL, H = int(g['num_layers']), int(g['num_heads'])
+    F = p['encoder.all_layers.0.ffn.ffn_1.weight'].shape[0]
+    vl, ids, tt = g['valid_length'], g['ids'], g['token_types']
+    for dtype, dn in ((torch.float32, 'float32'), (torch.bfloat16, 'bfloat16')):
+        m = BertModel(vocab_size=V, units=U, hidden_size=F, num_layers=NL, num_heads=H,
+                      max_length=p['token_pos_embed._embed.weight'].shape[0], dtype=dn).cuda()
+        load_parameters(m, os.path.join(G, 'bert_hf_h4' + suffix))
+        seq, pooled = m(torch.from_numpy(ids).cuda(), torch.from_numpy(tt).cuda(),
+                        torch.from_numpy(vl).cuda())
+        seq_n = to_np(seq)
+        if dtype == torch.float32:
+            want_seq, want_pooled, t = g['sequence'], g['pooled'], 1e-5
+        else:
+            f32 = {k: v.astype(np.float32) for k, v in p.items()}      # what the file holds
+            want_seq, want_pooled = bert_from_ids({k: prep(v, dtype) for k, v in f32.items()}, ids,
+                                                  tt, vl, NL, H)
+            t = 2e-2 * 1.5
+        for b in range(len(vl)):
+            assert rel_err(seq_n[b, :vl[b]], want_seq[b, :vl[b]]) < t, (dn, b)
+            assert (seq_n[b, vl[b]:] == 0).all()
+        assert rel_err(to_np(pooled), want_pooled) < t
