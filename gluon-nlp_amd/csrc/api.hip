@@ -905,7 +905,7 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
   int rc;
   for (int i = 0; i < n_layers; ++i) {
     const gnlp_t5_block_params *p = &layers[i];
-    REQUIRE(p->attn_ln_g && p->q_w && p->k_w && p->v_w && p->proj_w && p->ffn.ffn1_w &&
+    REQUIRE(p->attn_ln_g && (p->qkv_w || (p->q_w && p->k_w && p->v_w)) && p->proj_w && p->ffn.ffn1_w &&
             p->ffn.ffn2_w && p->ffn.ln_g, "missing weights in T5 block %d", i);
     const bool last = (i == n_layers - 1);
     void *dst = (last && !final_ln_g) ? out : pp[i & 1];
@@ -914,11 +914,17 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
                 cfg->ln_eps, M, D, nullptr, 0, 0, 0, 0, s);
     // t5.py:538-542  bias-free q / k / v projections written side by side: [q | k | v] rows
     char *qkv = base + w.qkv;
-    const void *wq[3] = {p->q_w, p->k_w, p->v_w};
-    for (int t = 0; t < 3; ++t) {
-      rc = dense_impl(qkv + (size_t)t * inner * e, base + w.normed, wq[t], nullptr, nullptr, 0,
-                      GNLP_ACT_IDENTITY, cfg->dtype, M, inner, D, D, 3 * inner, 0, s);
+    if (p->qkv_w) {   // the three weights packed row-wise: one GEMM of N = 3 * inner
+      rc = dense_impl(qkv, base + w.normed, p->qkv_w, nullptr, nullptr, 0, GNLP_ACT_IDENTITY,
+                      cfg->dtype, M, 3 * inner, D, D, 3 * inner, 0, s);
       if (rc) return rc;
+    } else {
+      const void *wq[3] = {p->q_w, p->k_w, p->v_w};
+      for (int t = 0; t < 3; ++t) {
+        rc = dense_impl(qkv + (size_t)t * inner * e, base + w.normed, wq[t], nullptr, nullptr, 0,
+                        GNLP_ACT_IDENTITY, cfg->dtype, M, inner, D, D, 3 * inner, 0, s);
+        if (rc) return rc;
+      }
     }
     gnlp_attn_desc ad;
     ad.B = B; ad.H = H; ad.Lq = L; ad.Lm = L; ad.dk = dkv; ad.dv = dkv;

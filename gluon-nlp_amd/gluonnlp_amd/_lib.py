@@ -54,7 +54,8 @@ class EncoderCfg(Structure):
 
 class T5BlockParams(Structure):
     _fields_ = [('attn_ln_g', c_void_p), ('attn_ln_b', c_void_p), ('q_w', c_void_p),
-                ('k_w', c_void_p), ('v_w', c_void_p), ('proj_w', c_void_p), ('ffn', FfnParams)]
+                ('k_w', c_void_p), ('v_w', c_void_p), ('proj_w', c_void_p), ('ffn', FfnParams),
+                ('qkv_w', c_void_p)]
 
 
 class T5Cfg(Structure):

@@ -23,6 +23,10 @@ def _normal(std):
     return init
 
 
+# developer knob (A/B only): GNLP_T5_PACK=0 issues the three projections as three GEMMs
+_PACK_QKV = __import__('os').environ.get('GNLP_T5_PACK', '1') != '0'
+
+
 class T5Block(nn.Module):
     """Pre-RMSNorm block with bias-free q/k/v/proj, ``scaled=False`` attention and the shared
     relative-position bias as ``edge_scores``.  models/t5.py:173-350, forward :492-572."""
@@ -85,6 +89,19 @@ class T5Block(nn.Module):
     def layout(self):
         return self._layout
 
+    def packed_qkv(self):
+        """[q; k; v] weights packed row-wise into one (3 * inner, d_model) buffer, so that the
+        block's three projections are ONE GEMM of N = 3 * inner (the reference keeps three Dense
+        layers, models/t5.py:296-318, and so do the parameter names here).  The copy is rebuilt
+        whenever one of the three parameters was replaced or edited in place."""
+        ws = [self.self_attn_q.weight.data, self.self_attn_k.weight.data,
+              self.self_attn_v.weight.data]
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        if getattr(self, '_qkv_key', None) != key:
+            self._qkv_packed = torch.cat(ws, dim=0).contiguous()
+            self._qkv_key = key
+        return self._qkv_packed
+
     def params_struct(self):
         p = _lib.T5BlockParams()
         p.attn_ln_g = T.ptr(self.self_attn_layer_norm.gamma.data)
@@ -92,6 +109,8 @@ class T5Block(nn.Module):
         p.q_w = T.ptr(self.self_attn_q.weight.data)
         p.k_w = T.ptr(self.self_attn_k.weight.data)
         p.v_w = T.ptr(self.self_attn_v.weight.data)
+        if _PACK_QKV:
+            p.qkv_w = T.ptr(self.packed_qkv())
         p.proj_w = T.ptr(self.self_attn_proj.weight.data)
         p.ffn = ffn_params_struct(self.ffn)
         return p

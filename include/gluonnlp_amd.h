@@ -324,6 +324,10 @@ typedef struct {
   const void *attn_ln_g, *attn_ln_b;     /* self_attn_layer_norm.gamma / .beta (beta may be NULL) */
   const void *q_w, *k_w, *v_w, *proj_w;  /* (inner, d_model) x3, (d_model, inner); bias-free */
   gnlp_ffn_params ffn;                   /* ffn.* (pre-norm RMS, optional gate) */
+  const void *qkv_w;                     /* optional: the three projection weights packed row-wise,
+                                            (3 * inner, d_model) = [q_w; k_w; v_w]; when non-NULL
+                                            ONE GEMM of N = 3 * inner replaces the three (same
+                                            results bit for bit); NULL = use q_w / k_w / v_w */
 } gnlp_t5_block_params;
 
 typedef struct {
