@@ -473,3 +473,84 @@ def test_sinusoidal_embedding_restatement():
                          ([torch.zeros(len(pos), 1, dtype=torch.float64)] if units % 2 else []), -1)
         assert got.shape == (len(pos), units)
         assert_allclose(got, want.numpy(), rtol=0, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------
+# backward pass: oracle gradients pinned to autograd through the reference's
+# PyTorch sibling (oracle/gen_golden_grad.py -> tests/golden/grad.npz)
+# ---------------------------------------------------------------------------------------------
+def _grad_cases(g):
+    for tag, biases in (('small', ('none', 'share', 'head')), ('d64', ('none', 'head'))):
+        for scaled in (1, 0):
+            for ename in biases:
+                yield tag, scaled, ename
+
+
+@pytest.mark.parametrize('layout', ['NKT', 'NTK', 'TNK'])
+def test_attention_backward_goldens(layout):
+    g = load('grad.npz')
+
+    def lay(x):    # goldens are stored NKT
+        return {'NKT': x, 'NTK': x.transpose(0, 2, 1, 3), 'TNK': x.transpose(2, 0, 1, 3)}[layout]
+
+    for tag, scaled, ename in _grad_cases(g):
+        q, k, v = [g['{}_{}'.format(tag, n)].astype(np.float64) for n in 'qkv']
+        e = None if ename == 'none' else g['{}_e_{}'.format(tag, ename)].astype(np.float64)
+        gc = g[tag + '_g_ctx'].astype(np.float64)
+        if layout == 'TNK':
+            gc = gc.transpose(1, 0, 2)
+        key = '{}_s{}_{}'.format(tag, scaled, ename)
+        ctx, _ = ref.multi_head_dot_attn(lay(q), lay(k), lay(v), g[tag + '_mask'], e,
+                                         scaled=bool(scaled), query_head_units=q.shape[-1],
+                                         layout=layout)
+        want_ctx = g[key + '_ctx']
+        assert_allclose(ctx if layout != 'TNK' else ctx.transpose(1, 0, 2), want_ctx,
+                        rtol=1e-12, atol=1e-12)
+        dq, dk, dv, de = ref.multi_head_dot_attn_backward(
+            gc, lay(q), lay(k), lay(v), g[tag + '_mask'], e, scaled=bool(scaled),
+            query_head_units=q.shape[-1], layout=layout)
+        for got, name in ((dq, 'dq'), (dk, 'dk'), (dv, 'dv')):
+            assert got.shape == lay(g[key + '_' + name]).shape
+            assert_allclose(got, lay(g[key + '_' + name]), rtol=1e-11, atol=1e-12, err_msg=key)
+        if e is None:
+            assert de is None
+        else:
+            assert de.shape == e.shape
+            assert_allclose(de, g[key + '_de'], rtol=1e-11, atol=1e-12, err_msg=key)
+    # the fully masked query row of the small case gets no gradient and gives none
+    assert not g['small_mask'][0, 3].any()
+    assert np.all(g['small_s1_head_dq'][0, :, 3] == 0)
+
+
+@pytest.mark.parametrize('tag', ['ln48', 'ln1024'])
+def test_layer_norm_backward_goldens(tag):
+    g = load('grad.npz')
+    x, gam, bet, go = [g['{}_{}'.format(tag, n)].astype(np.float64)
+                       for n in ('x', 'gamma', 'beta', 'g')]
+    eps = float(g[tag + '_eps'])
+    assert_allclose(ref.layer_norm(x, gam, bet, eps), g[tag + '_y'], rtol=1e-12, atol=1e-12)
+    dx, dgam, dbet = ref.layer_norm_backward(go, x, gam, eps)
+    assert_allclose(dx, g[tag + '_dx'], rtol=1e-10, atol=1e-12)
+    assert_allclose(dgam, g[tag + '_dgamma'], rtol=1e-10, atol=1e-12)
+    assert_allclose(dbet, g[tag + '_dbeta'], rtol=1e-10, atol=1e-12)
+
+
+def test_rms_norm_backward_by_finite_differences():
+    """No rms_norm gradient golden (the sibling has no RMSNorm layer): central differences of
+    the oracle's own forward, float64 -- parity unpinned beyond that."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 10))
+    gam = 1.0 + 0.1 * rng.standard_normal(10)
+    go = rng.standard_normal((3, 10))
+    dx, dgam, dbet = ref.rms_norm_backward(go, x, gam, 1e-6)
+    h = 1e-6
+    num = np.zeros_like(x)
+    for i in range(x.shape[0]):
+        for j in range(x.shape[1]):
+            xp, xm = x.copy(), x.copy()
+            xp[i, j] += h
+            xm[i, j] -= h
+            num[i, j] = ((ref.rms_norm(xp, gam, 0.0) - ref.rms_norm(xm, gam, 0.0)) * go).sum() / (2 * h)
+    assert_allclose(dx, num, rtol=1e-6, atol=1e-8)
+    assert_allclose(dgam, (go * x / np.sqrt((x * x).mean(-1, keepdims=True) + 1e-6)).sum(0))
+    assert_allclose(dbet, go.sum(0))
