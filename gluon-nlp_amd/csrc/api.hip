@@ -634,6 +634,113 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
                    workspace_bytes, S(stream));
 }
 
+size_t gnlp_attn_backward_workspace_bytes(const gnlp_attn_desc *d) {
+  if (!d || d->B < 0 || d->H < 0 || d->Lq < 0) return 0;
+  const size_t n = (size_t)d->B * (size_t)d->H * (size_t)d->Lq * 2 * sizeof(float);
+  return (n + 255) / 256 * 256;
+}
+
+int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edge,
+                                      int64_t d_edge_elems, const int64_t d_edge_stride[4],
+                                      const void *grad_ctx, const void *q, const void *k,
+                                      const void *v, const gnlp_attn_desc *d,
+                                      const gnlp_attn_grad_desc *gd, int dtype,
+                                      const uint8_t *mask, const int64_t mask_stride[3],
+                                      const void *valid_length, int vl_dtype,
+                                      const void *edge_scores, const int64_t edge_stride[4],
+                                      float temperature, void *workspace, size_t workspace_bytes,
+                                      gnlp_stream_t stream) {
+  REQUIRE(d != nullptr && gd != nullptr, "descriptor is NULL");
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(d->B >= 0 && d->H >= 0 && d->Lq >= 0 && d->Lm >= 0 && d->dk >= 0 && d->dv >= 0,
+          "negative shape");
+  REQUIRE(!mask || mask_stride, "mask given without strides");
+  REQUIRE(!edge_scores || edge_stride, "edge_scores given without strides");
+  REQUIRE(!d_edge || (edge_scores && d_edge_stride && d_edge_elems >= 0),
+          "d_edge needs edge_scores, its strides and its element count");
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
+  hipStream_t s = S(stream);
+  if (d_edge && d_edge_elems > 0) {
+    hipError_t e = hipMemsetAsync(d_edge, 0, (size_t)d_edge_elems * sizeof(float), s);
+    if (e != hipSuccess) return fail(GNLP_ERR_LAUNCH, "hipMemsetAsync(d_edge): %s", hipGetErrorString(e));
+  }
+  if (d->B * d->H == 0) return GNLP_OK;
+  if (d->Lq * d->Lm * d->dk * d->dv == 0)
+    return fail(GNLP_ERR_UNSUPPORTED, "attention backward with an empty axis (Lq=%lld Lm=%lld "
+                "dk=%lld dv=%lld): the gradients are all zero, fill them on the host side",
+                (long long)d->Lq, (long long)d->Lm, (long long)d->dk, (long long)d->dv);
+  REQUIRE(dq && dk && dv && grad_ctx && q && k && v, "NULL tensor");
+  GenAttnBwd a;
+  a.q = q; a.k = k; a.v = v; a.g = grad_ctx;
+  a.dq = dq; a.dk_out = dk; a.dv_out = dv;
+  a.de = d_edge;
+  a.B = d->B; a.H = d->H; a.Lq = d->Lq; a.Lm = d->Lm; a.dk = d->dk; a.dv = d->dv;
+  for (int i = 0; i < 3; ++i) {
+    a.qs[i] = d->q_stride[i]; a.ks[i] = d->k_stride[i]; a.vs[i] = d->v_stride[i];
+    a.gs[i] = gd->g_stride[i]; a.dqs[i] = gd->dq_stride[i]; a.dks[i] = gd->dk_stride[i];
+    a.dvs[i] = gd->dv_stride[i];
+    a.ms[i] = mask ? mask_stride[i] : 0;
+  }
+  for (int i = 0; i < 4; ++i) {
+    a.bs[i] = edge_scores ? edge_stride[i] : 0;
+    a.des[i] = d_edge ? d_edge_stride[i] : 0;
+  }
+  a.mask = mask;
+  a.vl = mask ? nullptr : valid_length;
+  a.vl_dtype = vl_dtype;
+  a.bias = edge_scores;
+  a.inv_temperature = temperature > 0.0f ? 1.0f / temperature : 1.0f;
+  if (!attn_bwd_supported(a))
+    return fail(GNLP_ERR_UNSUPPORTED, "attention backward: head dims %lld / %lld > 128 (or the "
+                "grid limit) are not supported", (long long)d->dk, (long long)d->dv);
+  const size_t need = gnlp_attn_backward_workspace_bytes(d);
+  REQUIRE(workspace && workspace_bytes >= need, "workspace too small (%zu < %zu)", workspace_bytes,
+          need);
+  REQUIRE(((uintptr_t)workspace & 3) == 0, "workspace must be 4-byte aligned");
+  a.stats = (float *)workspace;
+  launch_attn_bwd(a, dtype, s);
+  return check_launch("gnlp_multi_head_dot_attn_backward");
+}
+
+int gnlp_norm_backward(void *dx, float *dgamma, float *dbeta, const void *grad_out, const void *x,
+                       const void *residual, const void *gamma, int dtype, int kind, float eps,
+                       int64_t rows, int64_t C, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(kind == GNLP_NORM_LAYER || kind == GNLP_NORM_RMS || kind == GNLP_NORM_NONE,
+          "normalization kind %d is not supported", kind);
+  REQUIRE(rows >= 0 && C >= 0, "negative shape");
+  REQUIRE((dgamma && dbeta) || C == 0, "NULL dgamma / dbeta");
+  hipStream_t s = S(stream);
+  if (C > 0) {
+    hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
+    if (e != hipSuccess) return fail(GNLP_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  if (rows * C == 0) return GNLP_OK;
+  REQUIRE(dx && grad_out && x && gamma, "NULL tensor");
+  if (!norm_bwd_supported(C))
+    return fail(GNLP_ERR_UNSUPPORTED, "norm backward: C=%lld > %lld", (long long)C,
+                (long long)kNormBwdMaxC);
+  launch_norm_bwd(dx, dgamma, dbeta, grad_out, x, residual, gamma, dtype, kind, eps, rows, C, s);
+  return check_launch("gnlp_norm_backward");
+}
+
+int gnlp_l2_normalize_backward(void *dx, const void *grad_out, const void *x, int dtype,
+                               int64_t rows, int64_t d, float eps, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(rows >= 0 && d >= 0, "negative shape");
+  REQUIRE((dx && grad_out && x) || rows * d == 0, "NULL tensor");
+  launch_l2_normalize_bwd(dx, grad_out, x, dtype, rows, d, eps, S(stream));
+  return check_launch("gnlp_l2_normalize_backward");
+}
+
+int gnlp_cast_from_f32(void *out, int dtype, const float *in, int64_t n, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(n >= 0 && ((out && in) || n == 0), "bad arguments");
+  launch_cast_f32(out, dtype, in, n, S(stream));
+  return check_launch("gnlp_cast_from_f32");
+}
+
 int gnlp_gen_rel_position(int32_t *out, int64_t L, gnlp_stream_t stream) {
   REQUIRE(L >= 0 && (out || L == 0), "bad arguments");
   REQUIRE(L < 46341, "L too large for an (L, L) int32 index grid");

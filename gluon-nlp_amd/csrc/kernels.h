@@ -191,4 +191,34 @@ struct GenAttn {
 bool gen_attn_supported(const GenAttn &a);
 void launch_gen_attn(const GenAttn &a, int dtype, hipStream_t s);
 
+// attn_bwd.hip: gradients of the attention above w.r.t. q / k / v / edge scores
+struct GenAttnBwd {
+  const void *q, *k, *v, *g;            // g = cotangent of ctx
+  void *dq, *dk_out, *dv_out;           // tensor dtype
+  float *stats;                         // (B, H, Lq, 2) fp32 workspace: lse, D
+  float *de;                            // fp32, zero-filled, or null
+  int64_t B, H, Lq, Lm, dk, dv;
+  int64_t qs[3], ks[3], vs[3], gs[3], dqs[3], dks[3], dvs[3];   // (b, h, t) element strides
+  int64_t des[4];                       // (b, h, i, j); 0 along the axes the bias was broadcast
+  const uint8_t *mask;
+  int64_t ms[3];
+  const void *vl;
+  int vl_dtype;
+  const void *bias;
+  int64_t bs[4];
+  float inv_temperature;
+};
+bool attn_bwd_supported(const GenAttnBwd &a);
+void launch_attn_bwd(const GenAttnBwd &a, int dtype, hipStream_t s);
+
+// norm_bwd.hip
+constexpr int64_t kNormBwdMaxC = 8192;   // 2 * C fp32 LDS accumulators per workgroup
+bool norm_bwd_supported(int64_t C);
+void launch_norm_bwd(void *dx, float *dgamma, float *dbeta, const void *g, const void *x,
+                     const void *residual, const void *gamma, int dtype, int kind, float eps,
+                     int64_t rows, int64_t C, hipStream_t s);
+void launch_l2_normalize_bwd(void *dx, const void *g, const void *x, int dtype, int64_t rows,
+                             int64_t d, float eps, hipStream_t s);
+void launch_cast_f32(void *out, int dtype, const float *in, int64_t n, hipStream_t s);
+
 }  // namespace gnlp

@@ -31,6 +31,11 @@ class AttnDesc(Structure):
                 ('v_stride', c_int64 * 3), ('o_stride', c_int64 * 3)]
 
 
+class AttnGradDesc(Structure):
+    _fields_ = [('g_stride', c_int64 * 3), ('dq_stride', c_int64 * 3),
+                ('dk_stride', c_int64 * 3), ('dv_stride', c_int64 * 3)]
+
+
 class FfnParams(Structure):
     _fields_ = [('ffn1_w', c_void_p), ('ffn1_b', c_void_p), ('gate_w', c_void_p),
                 ('gate_b', c_void_p), ('ffn2_w', c_void_p), ('ffn2_b', c_void_p),
@@ -97,6 +102,19 @@ PROTOTYPES = {
                                          c_void_p, POINTER(AttnDesc), c_int, c_void_p,
                                          POINTER(c_int64), c_void_p, c_int, c_void_p,
                                          POINTER(c_int64), c_float, c_void_p, c_size_t, c_void_p]),
+    'gnlp_attn_backward_workspace_bytes': (c_size_t, [POINTER(AttnDesc)]),
+    'gnlp_multi_head_dot_attn_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                                  POINTER(c_int64), c_void_p, c_void_p, c_void_p,
+                                                  c_void_p, POINTER(AttnDesc),
+                                                  POINTER(AttnGradDesc), c_int, c_void_p,
+                                                  POINTER(c_int64), c_void_p, c_int, c_void_p,
+                                                  POINTER(c_int64), c_float, c_void_p, c_size_t,
+                                                  c_void_p]),
+    'gnlp_norm_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_int, c_float, c_int64, c_int64, c_void_p]),
+    'gnlp_l2_normalize_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
+                                           c_float, c_void_p]),
+    'gnlp_cast_from_f32': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     'gnlp_gen_rel_position': (c_int, [c_void_p, c_int64, c_void_p]),
     'gnlp_relative_position_bucket': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                               c_void_p]),

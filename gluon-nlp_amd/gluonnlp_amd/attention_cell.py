@@ -9,6 +9,7 @@ import torch
 
 from . import _lib
 from . import _tensor as T
+from .autograd import AttnFn, wants_grad
 from .op import l2_normalize
 
 __all__ = ['gen_self_attn_mask', 'gen_mem_attn_mask', 'masked_softmax', 'masked_logsoftmax',
@@ -166,7 +167,11 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
     ``scores`` / ``attn_weights`` (the encoder layers) pass ``_need_scores=False`` /
     ``_need_weights=False``: the list then holds ``None`` and, for bf16 with 64-wide heads, the
     fused kernel runs without ever forming the (B, H, Lq, Lm) tensor.  Dropout is inference-only
-    (identity); a non-zero rate is accepted and ignored like ``npx.dropout`` outside autograd."""
+    (identity); a non-zero rate is accepted and ignored like ``npx.dropout`` outside autograd.
+
+    Gradients: when torch autograd is recording and query / key / value / edge_scores require a
+    gradient, ``context_vec.backward()`` fills them through the HIP backward kernels
+    (gluonnlp_amd/autograd.py); ``scores`` / ``attn_weights`` are returned detached."""
     if normalized:
         query = l2_normalize(query, axis=-1, eps=eps)      # :435-437
         key = l2_normalize(key, axis=-1, eps=eps)
@@ -190,17 +195,19 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
     B, H, Lq = _bht_shape(q, layout)
     _, _, Lm = _bht_shape(k, layout)
     dk, dv = q.shape[-1], v.shape[-1]
-    d = _lib.AttnDesc()
-    d.B, d.H, d.Lq, d.Lm, d.dk, d.dv = B, H, Lq, Lm, dk, dv
-    d.q_stride[:] = _bht_strides(q, layout)
-    d.k_stride[:] = _bht_strides(k, layout)
-    d.v_stride[:] = _bht_strides(v, layout)
-    if layout == 'TNK':
-        ctx = torch.empty((Lq, B, H * dv), dtype=q.dtype, device=dev)
-        d.o_stride[:] = [H * dv, dv, B * H * dv]
-    else:
-        ctx = torch.empty((B, Lq, H * dv), dtype=q.dtype, device=dev)
-        d.o_stride[:] = [Lq * H * dv, dv, H * dv]
+
+    def desc(q, k, v):
+        d = _lib.AttnDesc()
+        d.B, d.H, d.Lq, d.Lm, d.dk, d.dv = B, H, Lq, Lm, dk, dv
+        d.q_stride[:] = _bht_strides(q, layout)
+        d.k_stride[:] = _bht_strides(k, layout)
+        d.v_stride[:] = _bht_strides(v, layout)
+        if layout == 'TNK':
+            d.o_stride[:] = [H * dv, dv, B * H * dv]
+        else:
+            d.o_stride[:] = [Lq * H * dv, dv, H * dv]
+        return d
+
     mptr, ms = None, None
     if m is not None:
         pred = mask_predicate(m) if _valid_length is None else None
@@ -209,40 +216,54 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
             kind, pvl = pred
             if kind == 'full':
                 vlt, vlp, vlc = T.valid_length_arg(pvl)
+            m = None
         else:
             if m.dtype != torch.bool:
                 m = m != 0                                  # :449
             m = torch.broadcast_to(m, (B, Lq, Lm))
             mptr, ms = T.ptr(m), (ctypes.c_int64 * 3)(*m.stride())
-            vlp = None
-    eptr, es = None, None
-    if e is not None:
-        if e.dtype != q.dtype:
-            e = e.to(q.dtype)
-        while e.dim() < 4:
-            e = e.unsqueeze(0)
-        e = torch.broadcast_to(e, (B, H, Lq, Lm))
-        eptr, es = T.ptr(e), (ctypes.c_int64 * 4)(*e.stride())
-    scores = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_scores else None
-    weights = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_weights else None
-    lib = _lib.load()
-    nws = lib.gnlp_attn_workspace_bytes(ctypes.byref(d), T.code(q), int(_need_scores),
-                                        int(_need_weights))
-    fused_ok = (not _need_scores and not _need_weights and q.dtype == torch.bfloat16
-                and dk == 64 and dv == 64)
-    ws = None if fused_ok else T.workspace(dev, nws)
-    rc = lib.gnlp_multi_head_dot_attn(
-        T.ptr(ctx), T.ptr(scores), T.ptr(weights), T.ptr(q), T.ptr(k), T.ptr(v),
-        ctypes.byref(d), T.code(q), mptr, ms, vlp, vlc, eptr, es,
-        0.0 if scale is None else float(scale), T.ptr(ws), 0 if ws is None else ws.numel(),
-        T.stream(dev))
-    if rc != 0 and fused_ok:        # fused kernel declined (alignment): retry with scratch
-        ws = T.workspace(dev, nws)
+            vlt, vlp = None, None
+    if e is not None and e.dtype != q.dtype:
+        e = e.to(q.dtype)
+    temperature = 0.0 if scale is None else float(scale)
+
+    def call(q, k, v, e):
+        d = desc(q, k, v)
+        ctx = torch.empty((Lq, B, H * dv) if layout == 'TNK' else (B, Lq, H * dv), dtype=q.dtype,
+                          device=dev)
+        eptr, es = None, None
+        if e is not None:
+            while e.dim() < 4:
+                e = e.unsqueeze(0)
+            e = torch.broadcast_to(e, (B, H, Lq, Lm))
+            eptr, es = T.ptr(e), (ctypes.c_int64 * 4)(*e.stride())
+        scores = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_scores else None
+        weights = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_weights else None
+        lib = _lib.load()
+        nws = lib.gnlp_attn_workspace_bytes(ctypes.byref(d), T.code(q), int(_need_scores),
+                                            int(_need_weights))
+        fused_ok = (not _need_scores and not _need_weights and q.dtype == torch.bfloat16
+                    and dk == 64 and dv == 64)
+        ws = None if fused_ok else T.workspace(dev, nws)
         rc = lib.gnlp_multi_head_dot_attn(
-            T.ptr(ctx), None, None, T.ptr(q), T.ptr(k), T.ptr(v), ctypes.byref(d), T.code(q),
-            mptr, ms, vlp, vlc, eptr, es, 0.0 if scale is None else float(scale), T.ptr(ws),
-            ws.numel(), T.stream(dev))
-    _lib.check(rc)
+            T.ptr(ctx), T.ptr(scores), T.ptr(weights), T.ptr(q), T.ptr(k), T.ptr(v),
+            ctypes.byref(d), T.code(q), mptr, ms, vlp, vlc, eptr, es, temperature, T.ptr(ws),
+            0 if ws is None else ws.numel(), T.stream(dev))
+        if rc != 0 and fused_ok:        # fused kernel declined (alignment): retry with scratch
+            ws = T.workspace(dev, nws)
+            rc = lib.gnlp_multi_head_dot_attn(
+                T.ptr(ctx), None, None, T.ptr(q), T.ptr(k), T.ptr(v), ctypes.byref(d), T.code(q),
+                mptr, ms, vlp, vlc, eptr, es, temperature, T.ptr(ws), ws.numel(), T.stream(dev))
+        _lib.check(rc)
+        return ctx, scores, weights
+
+    if wants_grad(q, k, v, e):
+        # gradients for query / key / value / edge_scores (tests/test_attention_cell.py:82-151)
+        ctx, scores, weights = AttnFn.apply(
+            q, k, v, e, call, {'layout': layout, 'desc': desc, 'bht': _bht_strides, 'mask': m,
+                               'vl': vlt, 'scale': temperature})
+    else:
+        ctx, scores, weights = call(q, k, v, e)
     return (T.like_caller(ctx, query),
             [T.like_caller(scores, query) if scores is not None else None,
              T.like_caller(weights, query) if weights is not None else None])

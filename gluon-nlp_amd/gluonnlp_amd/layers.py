@@ -12,6 +12,7 @@ from torch import nn
 
 from . import _lib
 from . import _tensor as T
+from .autograd import NormFn, wants_grad
 
 __all__ = ['PositionwiseFFN', 'GELU', 'get_activation', 'get_norm_layer', 'RMSNorm', 'NoNorm',
            'LayerNorm', 'Dense', 'BucketPositionalEmbedding', 'IdentityActivation', 'Activation',
@@ -19,6 +20,9 @@ __all__ = ['PositionwiseFFN', 'GELU', 'get_activation', 'get_norm_layer', 'RMSNo
 
 
 def _empty_param(shape, dtype):
+    # inference is the path: parameters are created frozen.  The norm layers' gamma / beta take a
+    # gradient once the caller flips ``requires_grad_(True)`` (autograd.NormFn); Dense has no
+    # backward kernel yet.
     return nn.Parameter(torch.zeros(shape, dtype=T.torch_dtype(dtype)), requires_grad=False)
 
 
@@ -115,14 +119,22 @@ def _norm_call(x, gamma, beta, kind, eps, residual=None):
     xt = T.as_tensor(x)
     rt = T.as_tensor(residual)
     dev = T.require_device(xt, rt, gamma, beta)
-    xt = xt.contiguous()
-    if rt is not None:
-        rt = rt.contiguous()
-    C = xt.shape[-1]
-    out = torch.empty_like(xt)
-    _lib.check(_lib.load().gnlp_norm(
-        T.ptr(out), T.ptr(xt), T.ptr(rt), T.ptr(gamma), T.ptr(beta), T.code(xt), kind, float(eps),
-        xt.numel() // max(C, 1), C, None, 0, 0, 0, 0, T.stream(dev)))
+
+    def call(xt, rt, gamma, beta):
+        xt = xt.contiguous()
+        if rt is not None:
+            rt = rt.contiguous()
+        C = xt.shape[-1]
+        out = torch.empty_like(xt)
+        _lib.check(_lib.load().gnlp_norm(
+            T.ptr(out), T.ptr(xt), T.ptr(rt), T.ptr(gamma), T.ptr(beta), T.code(xt), kind,
+            float(eps), xt.numel() // max(C, 1), C, None, 0, 0, 0, 0, T.stream(dev)))
+        return out
+
+    if wants_grad(xt, rt, gamma, beta):
+        out = NormFn.apply(xt, rt, gamma, beta, kind, eps, call)
+    else:
+        out = call(xt, rt, gamma, beta)
     return T.like_caller(out, x)
 
 
@@ -140,7 +152,7 @@ class LayerNorm(nn.Module):
         self.gamma.data.fill_(1.0)
 
     def forward(self, data, residual=None):
-        return _norm_call(data, self.gamma.data, self.beta.data, _lib.NORM['layer_norm'],
+        return _norm_call(data, self.gamma, self.beta, _lib.NORM['layer_norm'],
                           self._epsilon, residual)
 
 
@@ -157,7 +169,7 @@ class NoNorm(nn.Module):
         self.gamma.data.fill_(1.0)
 
     def forward(self, data):
-        return _norm_call(data, self.gamma.data, self.beta.data, _lib.NORM['no_norm'], 0.0)
+        return _norm_call(data, self.gamma, self.beta, _lib.NORM['no_norm'], 0.0)
 
 
 class RMSNorm(nn.Module):
@@ -174,7 +186,7 @@ class RMSNorm(nn.Module):
         self.gamma.data.fill_(1.0)
 
     def forward(self, data):
-        return _norm_call(data, self.gamma.data, self.beta.data, _lib.NORM['rms_norm'],
+        return _norm_call(data, self.gamma, self.beta, _lib.NORM['rms_norm'],
                           self._epsilon)
 
 

@@ -189,6 +189,61 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
                              size_t workspace_bytes, gnlp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Backward pass.  The reference takes these gradients with mx.autograd through
+ * the forward ops; its tests drive them through multi_head_dot_attn for query / key / value /
+ * rel_scores in every layout (tests/test_attention_cell.py:82-151) and through whole models
+ * (tests/test_models_bert.py).  Each call below is the vector-Jacobian product of one forward
+ * entry point of this header; nothing of size (B, H, Lq, Lm) is stored between forward and
+ * backward (the softmax is recomputed from q, k, edge_scores and the mask).
+ * ------------------------------------------------------------------------------------------- */
+
+/* VJP of gnlp_multi_head_dot_attn (attention_cell.py:332-524; normalized = False, no dropout)
+ * for grad_ctx = the cotangent of ctx:
+ *   P = masked_softmax((q k^T + edge) / t, mask),  dV = P^T dO,  dP = dO V^T,
+ *   dS = P (dP - rowsum(P dP)) / t,  dQ = dS k,  dK = dS^T q,  d_edge = dS.
+ * d, q, k, v, mask / valid_length, edge_scores, temperature: exactly as in the forward call.
+ * gd: (b, h, t) element strides of grad_ctx and of the three outputs (inner stride 1).
+ * d_edge: fp32, or NULL when the edge scores need no gradient.  It has the shape of the caller's
+ *   edge_scores BEFORE broadcasting: d_edge_stride[0..3] over (b, h, i, j) with 0 along every axis
+ *   the scores were broadcast along (the contributions are summed there); d_edge_elems = its
+ *   element count.  The call zero-fills it and accumulates with fp32 atomics (the summation order
+ *   over the broadcast axes is not fixed); cast with gnlp_cast_from_f32 if a bf16 copy is wanted.
+ * workspace: gnlp_attn_backward_workspace_bytes(d) bytes (two fp32 per (b, h, query) row).
+ * Head dims <= 128 (the general f32-MFMA kernels of attn_bwd.hip); larger: GNLP_ERR_UNSUPPORTED. */
+typedef struct {
+  int64_t g_stride[3], dq_stride[3], dk_stride[3], dv_stride[3];
+} gnlp_attn_grad_desc;
+
+size_t gnlp_attn_backward_workspace_bytes(const gnlp_attn_desc *d);
+
+int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edge,
+                                      int64_t d_edge_elems, const int64_t d_edge_stride[4],
+                                      const void *grad_ctx, const void *q, const void *k,
+                                      const void *v, const gnlp_attn_desc *d,
+                                      const gnlp_attn_grad_desc *gd, int dtype,
+                                      const uint8_t *mask, const int64_t mask_stride[3],
+                                      const void *valid_length, int vl_dtype,
+                                      const void *edge_scores, const int64_t edge_stride[4],
+                                      float temperature, void *workspace, size_t workspace_bytes,
+                                      gnlp_stream_t stream);
+
+/* VJP of gnlp_norm (without the fused sequence mask): dx (rows, C) in the tensor dtype -- it is
+ * also the gradient of `residual` when one was added --, dgamma / dbeta (C) in fp32 (zero-filled
+ * by the call, accumulated with fp32 atomics; dbeta may not be NULL).  x, residual, gamma, kind,
+ * eps: as in the forward call.  C <= 8192. */
+int gnlp_norm_backward(void *dx, float *dgamma, float *dbeta, const void *grad_out, const void *x,
+                       const void *residual, const void *gamma, int dtype, int kind, float eps,
+                       int64_t rows, int64_t C, gnlp_stream_t stream);
+
+/* VJP of gnlp_l2_normalize (op.py:289-307): dx = g / (n + eps) - x <g, x> / (n (n + eps)^2). */
+int gnlp_l2_normalize_backward(void *dx, const void *grad_out, const void *x, int dtype,
+                               int64_t rows, int64_t d, float eps, gnlp_stream_t stream);
+
+/* out[i] = (dtype) in[i]: the fp32 accumulators above -> a parameter's dtype.  No counterpart in
+ * the reference (MXNet accumulates in the parameter dtype). */
+int gnlp_cast_from_f32(void *out, int dtype, const float *in, int64_t n, gnlp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * T5 relative-position pieces
  * ------------------------------------------------------------------------------------------- */
 

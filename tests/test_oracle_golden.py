@@ -554,3 +554,20 @@ def test_rms_norm_backward_by_finite_differences():
     assert_allclose(dx, num, rtol=1e-6, atol=1e-8)
     assert_allclose(dgam, (go * x / np.sqrt((x * x).mean(-1, keepdims=True) + 1e-6)).sum(0))
     assert_allclose(dbet, go.sum(0))
+
+
+def test_l2_normalize_backward_by_finite_differences():
+    """No golden for this gradient: central differences of the oracle's own forward."""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((4, 7))
+    go = rng.standard_normal((4, 7))
+    dx = ref.l2_normalize_backward(go, x, -1, 1e-6)
+    h = 1e-6
+    num = np.zeros_like(x)
+    for i in range(x.shape[0]):
+        for j in range(x.shape[1]):
+            xp, xm = x.copy(), x.copy()
+            xp[i, j] += h
+            xm[i, j] -= h
+            num[i, j] = ((ref.l2_normalize(xp, -1, 1e-6) - ref.l2_normalize(xm, -1, 1e-6)) * go).sum() / (2 * h)
+    assert_allclose(dx, num, rtol=1e-6, atol=1e-8)
