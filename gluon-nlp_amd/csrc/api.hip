@@ -39,8 +39,6 @@ void reload_knobs() {
   k.group_m = env_int("GNLP_GROUP_M", 8, 1, 64);
   const int tile = env_int("GNLP_GEMM_TILE", 0, 0, 256);
   k.gemm_tile = (tile == 128 || tile == 256) ? tile : 0;
-  k.gemm_pp = env_on("GNLP_GEMM_PP");
-  k.gemm_ps = env_on("GNLP_GEMM_PS");
   k.gemm_w4 = env_on("GNLP_GEMM_W4");
   const int nt = env_int("GNLP_GEMM_NT", 0, 0, 256);
   k.gemm_nt = (nt == 192 || nt == 256) ? nt : 0;
@@ -214,6 +212,7 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     fa.mask = mask;
     if (mask) { fa.ms[0] = ms[0]; fa.ms[1] = ms[1]; fa.ms[2] = ms[2]; }
     fa.vl = vl; fa.vl_dtype = vl_dtype;
+    fa.causal = (!mask && d->causal) ? 1 : 0;
     fa.bias = edge;
     if (edge) for (int i = 0; i < 4; ++i) fa.bs[i] = es[i];
     fa.inv_temperature = inv_t;
@@ -234,6 +233,7 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     ga.mask = mask;
     if (mask) { ga.ms[0] = ms[0]; ga.ms[1] = ms[1]; ga.ms[2] = ms[2]; }
     ga.vl = vl; ga.vl_dtype = vl_dtype;
+    ga.causal = (!mask && d->causal) ? 1 : 0;
     ga.bias = edge;
     if (edge) for (int i = 0; i < 4; ++i) ga.bs[i] = es[i];
     ga.inv_temperature = inv_t;
@@ -243,6 +243,9 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
       return check_launch("general attention");
     }
   }
+  if (!mask && d->causal)
+    return fail(GNLP_ERR_UNSUPPORTED, "the in-kernel causal predicate needs head dims <= 128 "
+                "(dk=%lld dv=%lld): pass the byte mask", (long long)d->dk, (long long)d->dv);
   g_attn_kernel = GNLP_ATTN_KERNEL_UNFUSED;
   // ---- unfused path: scores -> masked softmax -> context (attention_cell.py:452-463) ----
   const size_t need = attn_ws_bytes(d, dtype, scores_out != nullptr, weights_out != nullptr, false);
@@ -407,6 +410,7 @@ int encoder_layer_impl(void *out, const void *x, const gnlp_encoder_layer_params
                   U, 3 * U, 0, s);  // :261
   if (rc) return rc;
   gnlp_attn_desc ad;
+  memset(&ad, 0, sizeof(ad));
   ad.B = B; ad.H = H; ad.Lq = L; ad.Lm = L; ad.dk = d; ad.dv = d;
   // rows are tokens: NT -> row = b*L + t ; TN -> row = t*B + b   (:262-264 reshape, :207 layout)
   const int64_t sb = c->time_major ? 1 : L, st = c->time_major ? B : 1;
@@ -627,6 +631,7 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
   REQUIRE(!edge_scores || edge_stride, "edge_scores given without strides");
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
   REQUIRE(d->B * d->H <= 0x7fffffffLL, "batch*heads too large");
+  REQUIRE(!(mask && d->causal), "d->causal selects the in-kernel predicate: mask must be NULL");
   if (d->B * d->H * d->Lq * d->dv == 0) return GNLP_OK;
   REQUIRE(ctx && q && k && v, "NULL tensor");
   return attn_impl(ctx, scores_out, weights_out, q, k, v, d, dtype, mask, mask_stride,
@@ -659,6 +664,7 @@ int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edg
   REQUIRE(!d_edge || (edge_scores && d_edge_stride && d_edge_elems >= 0),
           "d_edge needs edge_scores, its strides and its element count");
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
+  REQUIRE(!(mask && d->causal), "d->causal selects the in-kernel predicate: mask must be NULL");
   hipStream_t s = S(stream);
   if (d_edge && d_edge_elems > 0) {
     hipError_t e = hipMemsetAsync(d_edge, 0, (size_t)d_edge_elems * sizeof(float), s);
@@ -688,6 +694,7 @@ int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edg
   a.mask = mask;
   a.vl = mask ? nullptr : valid_length;
   a.vl_dtype = vl_dtype;
+  a.causal = (!mask && d->causal) ? 1 : 0;
   a.bias = edge_scores;
   a.inv_temperature = temperature > 0.0f ? 1.0f / temperature : 1.0f;
   if (!attn_bwd_supported(a))
@@ -1034,6 +1041,7 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
       }
     }
     gnlp_attn_desc ad;
+    memset(&ad, 0, sizeof(ad));
     ad.B = B; ad.H = H; ad.Lq = L; ad.Lm = L; ad.dk = dkv; ad.dv = dkv;
     const int64_t sb = cfg->time_major ? 1 : L, st = cfg->time_major ? B : 1;
     ad.q_stride[0] = ad.k_stride[0] = ad.v_stride[0] = sb * 3 * inner;

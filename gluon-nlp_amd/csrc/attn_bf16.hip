@@ -14,7 +14,8 @@
 //         transposing read ds_read_b64_tr_b16.
 // The NKT / NTK / TNK layouts and the fused-QKV buffer are stride descriptors.  The mask is either
 // the valid_length predicate (tiles beyond valid_length are skipped entirely, padded query rows
-// produce exact zeros) or a dense byte mask; edge_scores (T5 bias) is added before the
+// produce exact zeros), the causal predicate (j <= i) & (i < valid_length) (tiles above the block's
+// diagonal are skipped) or a dense byte mask; edge_scores (T5 bias) is added before the
 // temperature (attention_cell.py:453-455).
 #include "common.h"
 #include "kernels.h"
@@ -57,12 +58,17 @@ attn_fwd_bf16_d64(FusedAttn a) {
 
   int64_t kv_len = a.Lm;
   int64_t q_valid = a.Lq;
-  const bool use_pred = !DENSE_MASK && (a.vl != nullptr);
+  const bool causal = !DENSE_MASK && a.causal;   // (j <= i) & (i < vl): attention_cell.py:168-180
+  const bool use_pred = !DENSE_MASK && (a.vl != nullptr || causal);
   if (use_pred) {
-    int64_t n = load_len(a.vl, a.vl_dtype, b);
-    n = n < 0 ? 0 : n;
-    kv_len = n < a.Lm ? n : a.Lm;
-    q_valid = n < a.Lq ? n : a.Lq;
+    if (a.vl) {
+      int64_t n = load_len(a.vl, a.vl_dtype, b);
+      n = n < 0 ? 0 : n;
+      kv_len = n < a.Lm ? n : a.Lm;
+      q_valid = n < a.Lq ? n : a.Lq;
+    }
+    // key tiles entirely above the diagonal of this block's last row are never staged
+    if (causal && q0 + 128 < kv_len) kv_len = q0 + 128;
   }
   const int64_t my_q = q0 + wave * 32 + r;  // this lane's query row
   bf16 *const obase = (bf16 *)a.o + b * a.os[0] + h * a.os[1];
@@ -191,7 +197,9 @@ attn_fwd_bf16_d64(FusedAttn a) {
     // the wave grew by more than RESCALE_THR (log2 units), so that most tiles skip the O-wide
     // multiply; p is then bounded by 2^THR, harmless in bf16 (same relative precision).
     const int64_t kbase_idx = (int64_t)tile * KV_TILE;
-    const bool tail = DENSE_MASK || !rows_all_ok || (kbase_idx + KV_TILE > kv_len);
+    // (causal: the tile's last key lies beyond the wave's first row -> some (i, j) have j > i)
+    const bool tail = DENSE_MASK || !rows_all_ok || (kbase_idx + KV_TILE > kv_len) ||
+                      (causal && kbase_idx + KV_TILE - 1 > q0 + wave * 32);
     if (HAS_BIAS) {  // host guarantees unit key stride; loads may be unaligned
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -219,6 +227,7 @@ attn_fwd_bf16_d64(FusedAttn a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             bool on = row_ok && (jl + e) < kv_rem;
+            if (!DENSE_MASK && causal) on = on && (kbase_idx + jl + e) <= my_q;
             if (DENSE_MASK && on) on = mrow[(kbase_idx + jl + e) * a.ms[2]] != 0;
             sacc[kb][g * 4 + e] = on ? sacc[kb][g * 4 + e] : NEG_BIG;
           }

@@ -153,14 +153,19 @@ attn_bwd_q_kernel(GenAttnBwd a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t j = jb + row_of(e, hh);
-        if (j < a.Lm && row_on && (vlen < 0 || j < vlen)) on |= 1u << e;
+        if (j < a.Lm && row_on && (vlen < 0 || j < vlen) && (!a.causal || j <= my_q)) on |= 1u << e;
       }
     }
     return on;
   };
 
   const float inv_t = a.inv_temperature;
-  const int ntiles = (int)((a.Lm + BK - 1) / BK);
+  int64_t kv_end = a.Lm;   // causal predicate: key tiles above the workgroup's diagonal are skipped
+  if (a.causal && !a.mask) {
+    const int64_t qe = (qb + 1) * 32 * nwaves;
+    kv_end = qe < a.Lm ? qe : a.Lm;
+  }
+  const int ntiles = (int)((kv_end + BK - 1) / BK);
 
   // ---- pass 1: m, l and sum_j exp(x_j - m) dP_j, rescaled together ----
   float m_run = BWD_NEG, l_run = 0.0f, d_run = 0.0f;
@@ -343,7 +348,9 @@ attn_bwd_kv_kernel(GenAttnBwd a) {
 
   const float inv_t = a.inv_temperature;
   const int ntiles = (int)((a.Lq + BQ - 1) / BQ);
-  for (int t = 0; t < ntiles; ++t) {
+  // causal predicate: query tiles that end before the workgroup's first key see none of its keys
+  const int t0 = (a.causal && !a.mask) ? (int)((kbi * 32 * nwaves) / BQ) : 0;
+  for (int t = t0; t < ntiles; ++t) {
     __syncthreads();
     stage((int64_t)t * BQ);
     __syncthreads();
@@ -375,7 +382,7 @@ attn_bwd_kv_kernel(GenAttnBwd a) {
         if (on) {
           if (a.bias) x += ldf<T>(a.bias, b * a.bs[0] + h * a.bs[1] + i * a.bs[2] + my_k * a.bs[3]);
           if (a.mask) on = a.mask[b * a.ms[0] + i * a.ms[1] + my_k * a.ms[2]] != 0;
-          else on = vlen < 0 || i < vlen;
+          else on = (vlen < 0 || i < vlen) && (!a.causal || my_k <= i);
         }
         p[e] = on ? __expf(x * inv_t - Ls[r]) : 0.0f;
         ds[e] = p[e] * (dpacc[e] - Ds[r]) * inv_t;

@@ -162,7 +162,7 @@ attn_gen_kernel(GenAttn a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t j = jb + 8 * (e >> 2) + 4 * hh + (e & 3);
-        const bool ok = j < a.Lm && row_on && (vlen < 0 || j < vlen);
+        const bool ok = j < a.Lm && row_on && (vlen < 0 || j < vlen) && (!a.causal || j <= my_q);
         if (ok) on |= 1u << e;
       }
     }
@@ -170,7 +170,14 @@ attn_gen_kernel(GenAttn a) {
   };
 
   const float inv_t = a.inv_temperature;
-  const int ntiles = (int)((a.Lm + BK - 1) / BK);
+  // causal predicate and no (B, H, Lq, Lm) output to fill: the key tiles above the diagonal of the
+  // workgroup's last query row are skipped
+  int64_t kv_end = a.Lm;
+  if (a.causal && !a.mask && !a.scores_out && !a.weights_out) {
+    const int64_t qe = (qb + 1) * 32 * nwaves;
+    kv_end = qe < a.Lm ? qe : a.Lm;
+  }
+  const int ntiles = (int)((kv_end + BK - 1) / BK);
   constexpr bool two_pass = TWO_PASS;
   float m_run = GEN_NEG, l_run = 0.0f;
 

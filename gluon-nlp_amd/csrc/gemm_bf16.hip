@@ -228,20 +228,14 @@ void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void 
   // 256x256 tiles once they fill at least half of the 256 CUs (measured on T5-base, 192 tiles per
   // GEMM: +25 % end to end over 768 tiles of 128x128)
   const bool big = kn.gemm_tile ? (kn.gemm_tile == 256) : (t256 >= 128 && M >= 256 && N >= 256);
-  // one wave per SIMD (gemm_bf16_w4.hip) unless GNLP_GEMM_W4=0: more cycles per K-tile than the
-  // 8-wave kernel but a third less LDS traffic, and the chip holds a higher clock under it:
-  // 3050 -> 3230 seq/s on the BERT-large forward
-  if (big && kn.gemm_w4 && kn.gemm_pp && kn.gemm_ps &&
+  // persistent, one wave per SIMD (gemm_bf16_w4.hip) when the shape allows; otherwise (ragged M / N,
+  // N > 8192, or the developer knob GNLP_GEMM_W4=0) one 256x256 tile per workgroup with clamped
+  // edges (gemm_bf16_pp.hip) -- same accumulation order and epilogue, bit-identical results
+  if (big && kn.gemm_w4 &&
       mfma_bf16_dense_w4_supported(M, N, K, ldx, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_w4(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
-  else if (big && kn.gemm_pp && kn.gemm_ps &&
-      mfma_bf16_dense_ps_supported(M, N, K, ldx, ldo, ldother, out, bias, other))
-    launch_mfma_bf16_dense_ps(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
-  else if (big && kn.gemm_pp &&
-      mfma_bf16_dense_pp_supported(N, ldo, ldother, out, bias, other))
+  else if (big && mfma_bf16_dense_pp_supported(N, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_pp(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
-  else if (big)
-    launch_cfg<256, 256, 2, 4>(a, s);
   else
     launch_cfg<128, 128, 2, 2>(a, s);
 }

@@ -1,10 +1,11 @@
 // bf16 MFMA dense layer, PERSISTENT 256x256x64 kernel with ONE wave per SIMD (4 waves, each a
-// 128x128 block of the tile) for gfx950 -- the same GEMMs as gemm_bf16_ps.hip (QKV /
+// 128x128 block of the tile) for gfx950 -- the big GEMMs of the encoder layer (QKV /
 // attention_proj / FFN-1 / FFN-2 of models/transformer.py:193-206,261,266 and layers.py:590-612).
 //
 // Why this shape (it is the shape of the vendor library's hand-written 256x256x64 kernel): with 8
-// waves (128x64 each, gemm_bf16_ps.hip) a K-tile costs 192 KiB of LDS fragment reads and the two
-// waves of a SIMD trade the matrix pipe at barriers.  With 4 waves of 128x128 the fragment reads
+// waves (128x64 each: round 1's persistent kernel, retired in round 2) a
+// K-tile costs 192 KiB of LDS fragment reads and the two waves of a SIMD trade the matrix pipe at
+// barriers.  With 4 waves of 128x128 the fragment reads
 // drop to 128 KiB, each wave streams its 128 MFMAs per K-tile without handing the pipe over, and
 // the memory instructions (32 ds_read_b128 + 16 LDS-DMA per wave and K-tile) ride in the issue
 // slots between MFMAs.  256 accumulator registers + 128 fragment registers per lane: one wave per
@@ -37,8 +38,8 @@
 // store in full 128-byte lines through a 4 KiB LDS transpose image per wave) while the next
 // tile's first two K-tiles are already in flight.
 //
-// Same arithmetic, in the same order, as gemm_bf16_ps.hip / gemm_bf16_pp.hip: results are
-// bit-identical to theirs.
+// Same arithmetic, in the same order, as the one-tile-per-workgroup kernel gemm_bf16_pp.hip:
+// results are bit-identical to its (tests/test_gpu_ops.py).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -153,7 +154,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- the tiles of this workgroup (same walk as gemm_bf16_ps.hip) ----
+  // ---- the tiles of this workgroup (XCD-aware band walk) ----
   const int nt = a.tiles_m * a.tiles_n;
   const int S = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int q8 = nt >> 3, r8 = nt & 7;
@@ -492,9 +493,16 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
                                   int64_t ldother, const void *out, const void *bias,
                                   const void *other) {
-  // the same contract as the 8-wave persistent kernel, N a multiple of 256 or of 192
-  const int64_t N256 = N % 256 == 0 ? N : (N % 192 == 0 ? N / 192 * 256 : N);
-  return N <= 8192 && mfma_bf16_dense_ps_supported(M, N256, K, ldx, ldo, ldother, out, bias, other);
+  // M a multiple of 256; N a multiple of 256 or of 192; K a multiple of 64, at least two K-tiles
+  if (M % 256 != 0 || (N % 256 != 0 && N % 192 != 0) || N > 8192 || K % 64 != 0 || K < 128)
+    return false;
+  if (ldo % 8 != 0 || (other && ldother % 8 != 0)) return false;
+  if (((uintptr_t)out | (uintptr_t)(other ? other : out) | (uintptr_t)(bias ? bias : out)) % 16)
+    return false;
+  // per-lane staging offsets are 32-bit byte offsets inside a 256-row panel
+  if (256 * ldx * 2 >= ((int64_t)1 << 31) || 256 * K * 2 >= ((int64_t)1 << 31)) return false;
+  if ((M / 256) * ((N + 191) / 192) >= ((int64_t)1 << 28)) return false;
+  return true;
 }
 
 // Tile width for (M, N): 256 unless N is a multiple of 192 only, or both widths are a single

@@ -31,9 +31,7 @@ struct PerDeviceFlag {
 struct Knobs {
   int group_m;      // GNLP_GROUP_M: tile-walk band height, clamped to [1, 64]; default 8
   int gemm_tile;    // GNLP_GEMM_TILE: 0 = by shape, 128 / 256 forced
-  bool gemm_pp;     // GNLP_GEMM_PP=0: plain 2-phase loop instead of the ping-pong kernels
-  bool gemm_ps;     // GNLP_GEMM_PS=0: one tile per workgroup instead of the persistent kernels
-  bool gemm_w4;     // GNLP_GEMM_W4=0: the 8-wave persistent kernel instead of one wave per SIMD
+  bool gemm_w4;     // GNLP_GEMM_W4=0: one tile per workgroup (gemm_bf16_pp.hip) instead of the persistent kernel
   int gemm_nt;      // GNLP_GEMM_NT: 0 = by shape, 192 / 256 forced tile width
   bool norm_nt;     // GNLP_NORM_NT=0: plain instead of non-temporal loads in the norm kernel
   bool norm_full;   // GNLP_NORM_MAXV=f: always the full-width register image
@@ -125,15 +123,7 @@ bool mfma_bf16_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int
 void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void *bias,
                             const void *other, int combine, int act, int64_t M, int64_t N,
                             int64_t K, int64_t ldx, int64_t ldo, int64_t ldother, hipStream_t s);
-// Persistent form of the ping-pong kernel (gemm_bf16_ps.hip): M, N multiples of 256, K >= 128.
-bool mfma_bf16_dense_ps_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
-                                  int64_t ldother, const void *out, const void *bias,
-                                  const void *other);
-void launch_mfma_bf16_dense_ps(void *out, const void *x, const void *w, const void *bias,
-                               const void *other, int combine, int act, int64_t M, int64_t N,
-                               int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
-                               hipStream_t s);
-// One-wave-per-SIMD form (gemm_bf16_w4.hip): 4 waves of 128x128, same contract as the _ps kernel,
+// One-wave-per-SIMD form (gemm_bf16_w4.hip): PERSISTENT, 4 waves of 128x128; M a multiple of 256,
 // N a multiple of 256 or of 192 (256x192 tiles, 4 waves of 128x96).
 bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
                                   int64_t ldother, const void *out, const void *bias,
@@ -165,6 +155,7 @@ struct FusedAttn {
   int64_t ms[3];                        // (b, i, j)
   const void *vl;                       // or null (predicate i<vl && j<vl)
   int vl_dtype;
+  int causal;                           // mask null: predicate (j <= i) && (i < vl) instead
   const void *bias;                     // edge scores (bf16) or null
   int64_t bs[4];                        // (b, h, i, j)
   float inv_temperature;
@@ -184,6 +175,7 @@ struct GenAttn {
   int64_t ms[3];                        // (b, i, j)
   const void *vl;                       // or null (predicate i<vl && j<vl, used when mask is null)
   int vl_dtype;
+  int causal;                           // mask null: predicate (j <= i) && (i < vl) instead
   const void *bias;                     // edge scores (tensor dtype) or null
   int64_t bs[4];                        // (b, h, i, j)
   float inv_temperature;
@@ -204,6 +196,7 @@ struct GenAttnBwd {
   int64_t ms[3];
   const void *vl;
   int vl_dtype;
+  int causal;
   const void *bias;
   int64_t bs[4];
   float inv_temperature;

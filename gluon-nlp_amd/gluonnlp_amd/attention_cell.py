@@ -38,11 +38,15 @@ def _tag(mask, vl, kind):
     return mask
 
 
-def mask_predicate(mask):
-    """-> (kind, valid_length) if ``mask`` is an unmodified product of gen_self_attn_mask
-    ('full' / 'ones'), else None."""
+def mask_predicate(mask, causal=False):
+    """-> (kind, valid_length) if ``mask`` is an unmodified product of gen_self_attn_mask, else
+    None.  kind: 'full' ((i < vl) & (j < vl)), 'ones' (no valid_length), and -- only for callers
+    that pass ``causal=True`` because they can evaluate it -- 'causal' ((j <= i) & (i < vl),
+    valid_length possibly None); every other caller sees an untagged mask and reads its bytes."""
     kind = getattr(mask, '_gnlp_kind', None)
     if kind is None or getattr(mask, '_gnlp_version', -1) != mask._version:
+        return None
+    if kind == 'causal' and not causal:
         return None
     return kind, getattr(mask, '_gnlp_vl', None)
 
@@ -65,6 +69,8 @@ def gen_self_attn_mask(data, valid_length=None, dtype=None, attn_type: str = 'fu
         T.stream(dev)))
     if attn_type == 'full':
         _tag(mask, vlt, 'full' if vlt is not None else 'ones')
+    else:
+        _tag(mask, vlt, 'causal')
     return mask
 
 
@@ -199,6 +205,7 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
     def desc(q, k, v):
         d = _lib.AttnDesc()
         d.B, d.H, d.Lq, d.Lm, d.dk, d.dv = B, H, Lq, Lm, dk, dv
+        d.causal = int(causal)
         d.q_stride[:] = _bht_strides(q, layout)
         d.k_stride[:] = _bht_strides(k, layout)
         d.v_stride[:] = _bht_strides(v, layout)
@@ -209,13 +216,16 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
         return d
 
     mptr, ms = None, None
+    causal = False
     if m is not None:
-        pred = mask_predicate(m) if _valid_length is None else None
+        # (the causal predicate lives in the kernels for head dims <= 128)
+        pred = mask_predicate(m, causal=dk <= 128 and dv <= 128) if _valid_length is None else None
         if pred is not None and m.shape == (B, Lq, Lm) and Lq == Lm:
             # the mask came straight from gen_self_attn_mask: evaluate the predicate in-kernel
             kind, pvl = pred
-            if kind == 'full':
+            if kind in ('full', 'causal') and pvl is not None:
                 vlt, vlp, vlc = T.valid_length_arg(pvl)
+            causal = kind == 'causal'
             m = None
         else:
             if m.dtype != torch.bool:
@@ -315,13 +325,15 @@ class MultiHeadAttentionCell(torch.nn.Module):
 
 
 def gen_rel_position(data, past_data=None, dtype=None, layout='NT'):
-    """(L, L) int32 matrix of ``mem_j - query_i``.  attention_cell.py:611-656."""
-    if past_data is not None:
-        raise NotImplementedError('incremental decoding (past_data) is outside the encoder path')
+    """(L, L) int32 matrix of ``mem_j - query_i``.  attention_cell.py:611-656.  Under incremental
+    decoding (``past_data`` = the stacked previous steps, (B, L_past, H, d) / (L_past, B, H, d) or
+    already merged to 3-D) the positions run over the concatenated sequence, L = L_past + L_cur
+    (:644-652); only the time extents are read."""
     time_axis = 1 if layout == 'NT' else 0
     data = T.as_tensor(data)
-    dev = T.require_device(data)
-    L = data.shape[time_axis]
+    past = T.as_tensor(past_data)
+    dev = T.require_device(data, past)
+    L = data.shape[time_axis] + (past.shape[time_axis] if past is not None else 0)
     out = torch.empty((L, L), dtype=torch.int32, device=dev)
     _lib.check(_lib.load().gnlp_gen_rel_position(T.ptr(out), L, T.stream(dev)))
     return out

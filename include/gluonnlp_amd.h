@@ -151,7 +151,8 @@ int gnlp_dense(void *out, const void *x, const void *w, const void *bias, const 
  * q lives at q[b*q_stride[0] + h*q_stride[1] + t*q_stride[2] + c], likewise k, v and ctx.
  * mask: bytes (B, Lq, Lm) addressed with mask_stride[0..2], or NULL.
  * valid_length: if mask == NULL and valid_length != NULL the predicate (i < vl[b]) & (j < vl[b])
- *   is evaluated in-kernel (what gen_self_attn_mask 'full' would have produced).
+ *   is evaluated in-kernel (what gen_self_attn_mask 'full' would have produced); with d->causal
+ *   the predicate is (j <= i) & (i < vl[b]) (gen_self_attn_mask 'causal').
  * edge_scores: addressed with edge_stride[0..3] over (b, h, i, j) (0 = broadcast) or NULL; it is
  *   added BEFORE the temperature (attention_cell.py:453-455).
  * temperature: sqrt(query_head_units) when scaled, 0 / 1 otherwise.
@@ -167,6 +168,10 @@ int gnlp_dense(void *out, const void *x, const void *w, const void *bias, const 
 typedef struct {
   int64_t B, H, Lq, Lm, dk, dv;
   int64_t q_stride[3], k_stride[3], v_stride[3], o_stride[3]; /* (b, h, t) element strides */
+  int64_t causal; /* != 0 (mask must be NULL, head dims <= 128): the in-kernel predicate is
+                     gen_self_attn_mask(attn_type='causal')'s (attention_cell.py:168-180),
+                     (j <= i) & (i < valid_length[b]) -- valid_length may be NULL (lower triangle);
+                     key tiles above the diagonal are skipped */
 } gnlp_attn_desc;
 
 size_t gnlp_attn_workspace_bytes(const gnlp_attn_desc *d, int dtype, int want_scores,

@@ -460,3 +460,64 @@ def test_rccl_gather_path_single_rank(nlp, tmp_path):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------- causal predicate
+@pytest.mark.parametrize('dtype,d', [(torch.bfloat16, 64), (torch.float32, 64), (torch.float32, 8),
+                                     (torch.bfloat16, 128)])
+@pytest.mark.parametrize('L', [200, 512, 31])
+@pytest.mark.parametrize('use_vl,use_bias', [(True, False), (False, True), (True, True)])
+def test_causal_predicate_matches_mask_bytes(nlp, dtype, d, L, use_vl, use_bias):
+    """A mask straight from gen_self_attn_mask(attn_type='causal') is evaluated in-kernel as
+    (j <= i) & (i < valid_length) (attention_cell.py:168-180), key tiles above the diagonal are
+    skipped: same answers as the same bytes handed over untagged, and as the oracle."""
+    from gluonnlp_amd import _lib
+    ac = nlp.attention_cell
+    rng = np.random.default_rng(L + d)
+    B, H = 3, 2
+    q, k, v = [rng.standard_normal((B, L, H, d)) for _ in range(3)]
+    vl = np.array([L, 1, max(2, L * 3 // 5)]) if use_vl else None
+    e = rng.standard_normal((H, L, L)) if use_bias else None
+    data = torch.zeros((B, L, 1), device='cuda')
+    mask = ac.gen_self_attn_mask(data, None if vl is None else torch.tensor(vl, device='cuda'),
+                                 attn_type='causal')
+    assert ac.mask_predicate(mask) is None                      # opt-in only
+    assert ac.mask_predicate(mask, causal=True)[0] == 'causal'
+    dense = mask.clone()
+    assert np.array_equal(dense.cpu().numpy(), ref.gen_self_attn_mask((B, L), vl, attn_type='causal'))
+    qq, kk, vv = [to_dev(x, dtype) for x in (q, k, v)]
+    ee = None if e is None else to_dev(e, dtype)
+    kw = dict(scaled=True, query_head_units=d, layout='NTK')
+    fused = dtype == torch.bfloat16 and d == 64
+    a, _ = ac.multi_head_dot_attn(qq, kk, vv, mask, ee, _need_scores=False, _need_weights=False, **kw)
+    assert _lib.load().gnlp_attn_last_kernel() == (
+        _lib.ATTN_KERNEL_FUSED_BF16 if fused else _lib.ATTN_KERNEL_GENERAL_MFMA)
+    b, _ = ac.multi_head_dot_attn(qq, kk, vv, dense, ee, _need_scores=False, _need_weights=False, **kw)
+    assert torch.equal(a, b)
+    exp, (es, ew) = ref.multi_head_dot_attn(
+        prep(q, dtype), prep(k, dtype), prep(v, dtype), dense.cpu().numpy(),
+        None if e is None else prep(e, dtype), scaled=True, query_head_units=d, layout='NTK')
+    assert rel_err(to_np(a), exp) < tol(dtype)
+    # with scores / weights wanted nothing may be skipped: the whole (B, H, L, L) is written
+    c, (s, w) = ac.multi_head_dot_attn(qq, kk, vv, mask, ee, **kw)
+    assert rel_err(to_np(c), exp) < tol(dtype)
+    assert rel_err(to_np(s), es) < tol(dtype) and rel_err(to_np(w), ew) < tol(dtype)
+    assert (to_np(w)[np.broadcast_to(~dense.cpu().numpy()[:, None], w.shape)] == 0).all()
+
+
+def test_causal_tagged_mask_is_not_ones_for_the_layers(nlp):
+    """The encoder layer and the T5 block only know the 'full' predicate: a causal-tagged mask must
+    reach them as bytes (GPT-style use of an encoder layer), not as 'no mask'."""
+    from gluonnlp_amd.models.transformer import TransformerEncoderLayer
+    torch.manual_seed(0)
+    B, L, U, H = 2, 24, 64, 4
+    layer = TransformerEncoderLayer(units=U, hidden_size=128, num_heads=H, dtype='float32').cuda()
+    for p in layer.parameters():
+        p.data.normal_(0, 0.1)
+    x = torch.randn(B, L, U, device='cuda')
+    mask = nlp.attention_cell.gen_self_attn_mask(x, None, attn_type='causal')
+    out_tag, _ = layer(x, mask)
+    out_bytes, _ = layer(x, mask.clone())
+    out_ones, _ = layer(x, torch.ones_like(mask))
+    assert torch.equal(out_tag, out_bytes)
+    assert not torch.allclose(out_tag, out_ones)

@@ -200,6 +200,14 @@ def test_rel_position_and_t5_bias(nlp):
     exp = ref.gen_rel_position((2, L))
     assert np.array_equal(rp.cpu().numpy(), exp)
     assert np.array_equal(ac.gen_rel_position(data.transpose(0, 1), layout='TN').cpu().numpy(), exp)
+    # incremental decoding (attention_cell.py:644-652): positions over [past_data, data]
+    step = torch.zeros((2, 1, 4), device='cuda')
+    past = torch.zeros((2, 6, 3, 8), device='cuda')                       # (B, L_past, H, d_kv)
+    rp7 = ac.gen_rel_position(step, past_data=past)
+    assert np.array_equal(rp7.cpu().numpy(), ref.gen_rel_position((2, 1, 4), (2, 6, 3, 8)))
+    assert tuple(rp7.shape) == (7, 7) and int(rp7[6, 0]) == -6
+    rp7t = ac.gen_rel_position(step.transpose(0, 1), past_data=past.transpose(0, 1), layout='TN')
+    assert torch.equal(rp7, rp7t)
     # dense (L, L) grid of buckets at the cfg4 size: bit-exact
     b = nlp.op.relative_position_bucket(rp)
     assert np.array_equal(b.cpu().numpy(), ref.relative_position_bucket(exp))
@@ -310,21 +318,15 @@ def test_dense_persistent(nlp, M, N, K, monkeypatch):
     for g, h in zip(got, variants()):
         assert torch.equal(g, h)
     try:
-        # the three 256x256x64 kernels -- one wave per SIMD (gemm_bf16_w4.hip, the default), 8
-        # waves persistent (gemm_bf16_ps.hip), one tile per workgroup (gemm_bf16_pp.hip) --
+        # the two 256x256x64 kernels -- persistent with one wave per SIMD (gemm_bf16_w4.hip, the
+        # default) and one tile per workgroup (gemm_bf16_pp.hip, what ragged shapes take) --
         # accumulate in the same order with the same fp32 epilogue: bit for bit equal
-        monkeypatch.setenv('GNLP_GEMM_PS', '0')
-        reload_knobs()
-        for g, h in zip(got, variants()):
-            assert torch.equal(g, h)
-        monkeypatch.delenv('GNLP_GEMM_PS')
         monkeypatch.setenv('GNLP_GEMM_W4', '0')
         reload_knobs()
         for g, h in zip(got, variants()):
             assert torch.equal(g, h)
     finally:
-        for k in ('GNLP_GEMM_W4', 'GNLP_GEMM_PS'):
-            monkeypatch.delenv(k, raising=False)
+        monkeypatch.delenv('GNLP_GEMM_W4', raising=False)
         reload_knobs()
 
 

@@ -233,6 +233,9 @@ def test_bucket_properties():
     g = ref.gen_rel_position((2, 7, 3))
     assert g.dtype == np.int32 and g.shape == (7, 7)
     assert g[2, 5] == 3 and g[5, 2] == -3              # mem_j - query_i
+    gp = ref.gen_rel_position((2, 1, 3), past_data=(2, 6, 4, 8))       # :644-652
+    assert_array_equal(gp, g)
+    assert_array_equal(ref.gen_rel_position((1, 2, 3), past_data=(6, 2, 4, 8), layout='TN'), g)
     w = np.random.default_rng(0).standard_normal((32, 4))
     s = ref.rel_attention_score_t5(w, g)
     assert s.shape == (4, 7, 7)

@@ -1,10 +1,10 @@
 """Static check of the persistent GEMM's hand-counted global loads (developer tool).
 
-For every inline-asm `global_load_dwordx4 v[a:b], ...` in the dense_bf16_ps kernels of an
+For every inline-asm `global_load_dwordx4 v[a:b], ...` in the dense_bf16_w4 kernels of an
 assembly listing, the first later instruction that names one of v[a..b] must come AFTER an
 `s_waitcnt vmcnt(...)`: the compiler believes the asm output is valid at once, so a copy or a
 use placed before the wait would read the register before the load has landed.
-Usage: hipcc -S --cuda-device-only ... -o ps.s gemm_bf16_ps.hip; python check_async_regs.py ps.s
+Usage: hipcc -S --cuda-device-only ... -o w4.s gemm_bf16_w4.hip; python check_async_regs.py w4.s
 """
 import re
 import sys
@@ -24,7 +24,7 @@ def main(path):
     checked = 0
     kernel = None
     for i, ln in enumerate(lines):
-        m = re.match(r'^(_ZN4gnlp20dense_bf16_ps_kernel\w+):', ln)
+        m = re.match(r'^(_ZN4gnlp20dense_bf16_w4_kernel\w+):', ln)
         if m:
             kernel = m.group(1)
         if ln.startswith('.Lfunc_end'):

@@ -16,7 +16,7 @@ for r in csv.DictReader(open(kt)):
 rows = []
 for r in csv.DictReader(open(cc)):
     d = dur.get(r['Dispatch_Id'])
-    if d and 'dense_bf16_ps' in d[1]:
+    if d and 'dense_bf16_' in d[1]:
         rows.append((int(r['Dispatch_Id']), float(r['Counter_Value']), d[0]))
 rows.sort()
 # gemm_power.py: per kind and shape 35 launches

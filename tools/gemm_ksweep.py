@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from gemm_bench import run
 M = 32768
 for ps in os.environ.get('PSVALS', '1,0').split(','):
-    __import__('gluonnlp_amd._lib', fromlist=['x']).set_knob('GNLP_GEMM_PS', ps)
+    __import__('gluonnlp_amd._lib', fromlist=['x']).set_knob('GNLP_GEMM_W4', ps)
     for N, act, other in ((4096, 'identity', False), (4096, 'gelu', False), (1024, 'identity', True)):
         ts = []
         for K in (512, 1024, 2048, 4096):

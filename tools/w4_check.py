@@ -1,4 +1,4 @@
-"""Developer tool: the one-wave-per-SIMD GEMM (GNLP_GEMM_W4=1) against the 8-wave persistent
+"""Developer tool: the one-wave-per-SIMD GEMM (GNLP_GEMM_W4=1) against the one-tile-per-workgroup
 kernel, bit for bit, on the BERT shapes and a few awkward ones; then timings of both."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """Developer tool (run under rocprofv3 --pmc GRBM_GUI_ACTIVE by tools/w4_clock.sh): the FFN-2 shape
-on the 8-wave kernel, the one-wave-per-SIMD kernel and the vendor library's kernel."""
+on the one-tile-per-workgroup kernel (GNLP_GEMM_W4=0), the one-wave-per-SIMD kernel and the vendor library's kernel."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gluon-nlp_amd'))
