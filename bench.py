@@ -285,6 +285,8 @@ def main():
     if rank == 0:
         seqs = world * B * args.steps / elapsed
         fps = flops_per_seq(U, F, layers, L)
+        vls = vl.to(torch.float64)
+        useful_fps = float((layers * (vls * (8 * U * U + 4 * U * F) + 4 * vls * vls * U)).mean())
         peak = PEAK[args.dtype]
         # dominant kernel: FFN-1 GEMM + bias + erf-GELU epilogue (M x F x U), one launch per layer
         M = B * L
@@ -302,7 +304,7 @@ def main():
         achieved = kflops / (ms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch of the dominant kernel, from the separate PMC passes
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r02a_hbm_traffic_pmc.json')))
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r02b_hbm_traffic_pmc.json')))
             for k, v in tj.items():
                 if 'dense_bf16_w4' in k and '<2' in k and args.config == 'bert_large' and act == 'gelu':
                     traffic = (v['fetch_MB_corrected_x2'] + v['write_MB']) * 1048576.0
@@ -328,6 +330,10 @@ def main():
             'reference_harness_protocol_ms': harness_ms, 'median_of_20_ms': median_ms,
             'path_tflops': seqs * fps / 1e12,
             'path_frac_of_mfma_peak': seqs * fps / 1e12 / (peak * world),
+            # ragged configs are priced both ways -- dense over the padded length
+            # (above) and "useful": only the valid tokens' contractions, attention over vl x vl
+            'path_tflops_useful': seqs * useful_fps / 1e12,
+            'path_frac_of_mfma_peak_useful': seqs * useful_fps / 1e12 / (peak * world),
             'roofline': {'bound': 'mfma',
                          'kernel': '{} (FFN-1 GEMM + bias + {}), M={} N={} K={}'.format(
                              'dense_bf16_w4_kernel' if args.dtype == 'bf16' else 'dense_f32_kernel',

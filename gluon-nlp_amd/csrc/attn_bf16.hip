@@ -30,7 +30,7 @@ constexpr int KV_TILE = 64;
 constexpr int TILE_BYTES = KV_TILE * 128;   // 64 keys x 64 bf16
 constexpr float NEG_BIG = -1.0e30f;
 
-template <bool HAS_BIAS, bool DENSE_MASK>
+template <bool HAS_BIAS, bool DENSE_MASK, bool CAUSAL>
 __global__ void __launch_bounds__(256, 2)
 attn_fwd_bf16_d64(FusedAttn a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
@@ -58,7 +58,7 @@ attn_fwd_bf16_d64(FusedAttn a) {
 
   int64_t kv_len = a.Lm;
   int64_t q_valid = a.Lq;
-  const bool causal = !DENSE_MASK && a.causal;   // (j <= i) & (i < vl): attention_cell.py:168-180
+  constexpr bool causal = !DENSE_MASK && CAUSAL;   // (j <= i) & (i < vl): attention_cell.py:168-180
   const bool use_pred = !DENSE_MASK && (a.vl != nullptr || causal);
   if (use_pred) {
     if (a.vl) {
@@ -358,12 +358,16 @@ bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv) {
 
 void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s) {
   dim3 grid((unsigned)((a.Lq + 127) / 128), (unsigned)a.H, (unsigned)a.B);
+  // (the causal predicate is a template argument: as a run-time flag it cost the full-length
+  // non-causal case 20 %: 102 -> 123 us per launch at the BERT-large shape)
   if (a.bias) {
-    if (a.mask) attn_fwd_bf16_d64<true, true><<<grid, 256, 0, s>>>(a);
-    else attn_fwd_bf16_d64<true, false><<<grid, 256, 0, s>>>(a);
+    if (a.mask) attn_fwd_bf16_d64<true, true, false><<<grid, 256, 0, s>>>(a);
+    else if (a.causal) attn_fwd_bf16_d64<true, false, true><<<grid, 256, 0, s>>>(a);
+    else attn_fwd_bf16_d64<true, false, false><<<grid, 256, 0, s>>>(a);
   } else {
-    if (a.mask) attn_fwd_bf16_d64<false, true><<<grid, 256, 0, s>>>(a);
-    else attn_fwd_bf16_d64<false, false><<<grid, 256, 0, s>>>(a);
+    if (a.mask) attn_fwd_bf16_d64<false, true, false><<<grid, 256, 0, s>>>(a);
+    else if (a.causal) attn_fwd_bf16_d64<false, false, true><<<grid, 256, 0, s>>>(a);
+    else attn_fwd_bf16_d64<false, false, false><<<grid, 256, 0, s>>>(a);
   }
 }
 
