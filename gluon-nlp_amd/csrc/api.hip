@@ -43,6 +43,7 @@ void reload_knobs() {
   const int nt = env_int("GNLP_GEMM_NT", 0, 0, 256);
   k.gemm_nt = (nt == 192 || nt == 256) ? nt : 0;
   k.norm_nt = env_on("GNLP_NORM_NT");
+  k.pack_ragged = env_on("GNLP_PACK_RAGGED");
   const char *mv = getenv("GNLP_NORM_MAXV");
   k.norm_full = mv && mv[0] == 'f';
   g_knobs = k;
@@ -58,6 +59,17 @@ namespace {
 
 thread_local std::string g_err;
 thread_local int g_attn_kernel = 0;   // which kernel the last attention dispatch on this thread took
+thread_local const int32_t *g_rows_dev = nullptr;   // see dense_rows_dev() in kernels.h
+thread_local int g_stack_packed = 0;   // whether the last stack call on this thread ran packed
+}  // namespace
+namespace gnlp {
+const int32_t *dense_rows_dev() { return g_rows_dev; }
+}  // namespace gnlp
+namespace {
+struct RowsDevScope {   // set for the calls of one packed stack, cleared on every way out
+  explicit RowsDevScope(const int32_t *p) { g_rows_dev = p; }
+  ~RowsDevScope() { g_rows_dev = nullptr; }
+};
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -204,11 +216,13 @@ bool can_fuse(const gnlp_attn_desc *d, int dtype, const void *q, const void *k, 
 int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, const void *k,
               const void *v, const gnlp_attn_desc *d, int dtype, const uint8_t *mask,
               const int64_t *ms, const void *vl, int vl_dtype, const void *edge, const int64_t *es,
-              float temperature, void *ws, size_t ws_bytes, hipStream_t s) {
+              float temperature, void *ws, size_t ws_bytes, hipStream_t s,
+              const int32_t *cu = nullptr) {
   if (d->B == 0 || d->H == 0 || d->Lq == 0) return GNLP_OK;
   const float inv_t = temperature > 0.0f ? 1.0f / temperature : 1.0f;
   FusedAttn fa;
   if (!scores_out && !weights_out && can_fuse(d, dtype, q, k, v, ctx, edge, es, &fa)) {
+    fa.cu = cu;
     fa.mask = mask;
     if (mask) { fa.ms[0] = ms[0]; fa.ms[1] = ms[1]; fa.ms[2] = ms[2]; }
     fa.vl = vl; fa.vl_dtype = vl_dtype;
@@ -220,6 +234,7 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     g_attn_kernel = GNLP_ATTN_KERNEL_FUSED_BF16;
     return check_launch("fused attention");
   }
+  if (cu) return fail(GNLP_ERR_UNSUPPORTED, "packed batches need the fused bf16 attention kernel");
   {   // ---- general MFMA kernel: fp32, other head dims, scores / weights wanted; no workspace ----
     GenAttn ga;
     memset(&ga, 0, sizeof(ga));
@@ -390,7 +405,9 @@ EncWs enc_ws(const gnlp_encoder_cfg *c, int64_t B, int64_t L, bool want_weights)
 int encoder_layer_impl(void *out, const void *x, const gnlp_encoder_layer_params *p,
                        const gnlp_encoder_cfg *c, int64_t B, int64_t L, const uint8_t *mask,
                        const void *vl, int vl_dtype, void *attn_w_out, int final_seq_mask,
-                       void *ws, size_t ws_bytes, hipStream_t s) {
+                       void *ws, size_t ws_bytes, hipStream_t s, const int32_t *cu = nullptr) {
+  // cu != null: x / out hold the batch PACKED to its valid tokens (row cu[b] + t); the dense
+  // kernels read the row count from device memory (RowsDevScope of the caller), M stays the bound
   const int64_t U = c->units, H = c->heads, M = B * L, d = U / H;
   const EncWs w = enc_ws(c, B, L, attn_w_out != nullptr);
   REQUIRE(ws && ws_bytes >= w.total, "encoder workspace too small: need %zu bytes, got %zu",
@@ -413,7 +430,7 @@ int encoder_layer_impl(void *out, const void *x, const gnlp_encoder_layer_params
   memset(&ad, 0, sizeof(ad));
   ad.B = B; ad.H = H; ad.Lq = L; ad.Lm = L; ad.dk = d; ad.dv = d;
   // rows are tokens: NT -> row = b*L + t ; TN -> row = t*B + b   (:262-264 reshape, :207 layout)
-  const int64_t sb = c->time_major ? 1 : L, st = c->time_major ? B : 1;
+  const int64_t sb = cu ? 0 : (c->time_major ? 1 : L), st = cu ? 1 : (c->time_major ? B : 1);
   for (int i = 0; i < 1; ++i) {
     ad.q_stride[0] = ad.k_stride[0] = ad.v_stride[0] = sb * 3 * U;
     ad.q_stride[1] = ad.k_stride[1] = ad.v_stride[1] = d;
@@ -423,7 +440,7 @@ int encoder_layer_impl(void *out, const void *x, const gnlp_encoder_layer_params
   const int64_t mstr[3] = {L * L, L, 1};
   rc = attn_impl(base + w.ctx, nullptr, attn_w_out, qkv, qkv + (size_t)U * e,
                  qkv + (size_t)2 * U * e, &ad, c->dtype, mask, mstr, vl, vl_dtype, nullptr, nullptr,
-                 sqrtf((float)d), base + w.attn, w.ffn - w.attn, s);  // :265, scaled=True :213
+                 sqrtf((float)d), base + w.attn, w.ffn - w.attn, s, cu);  // :265, scaled=True :213
   if (rc) return rc;
   // :266-268  out = attention_proj(ctx) + data   (data = normalised input when pre_norm)
   rc = dense_impl(base + w.sum, base + w.ctx, p->proj_w, p->proj_b, in, GNLP_COMBINE_ADD,
@@ -465,6 +482,24 @@ int static_scratch(void **ptr) {
   return GNLP_OK;
 }
 
+// Whether a ragged batch may run packed to its valid tokens: bf16, every GEMM of the layer takes the
+// persistent kernel (the one that reads the row count from device memory) at the padded size, the
+// attention call takes the fused kernel, rows move as 16-byte vectors, offsets fit int32.
+bool stack_can_pack(const gnlp_encoder_cfg *c, int64_t B, int64_t L, const void *ws,
+                    const gnlp_encoder_layer_params *layers) {
+  const int64_t U = c->units, F = c->hidden, M = B * L;
+  if (c->dtype != GNLP_BF16 || M % 256 != 0 || M >= ((int64_t)1 << 31) || U % 8 != 0) return false;
+  if (!stack_attn_fuses(c->dtype, B, c->heads, U / c->heads, 3 * U, U)) return false;
+  const gnlp_encoder_layer_params *p = &layers[0];
+  if (!p->qkv_b || !p->proj_b || !p->ffn.ffn1_b || !p->ffn.ffn2_b) return false;   // (any is fine;
+  // the alignment checks below only need representative pointers: workspace and parameter rows)
+  return mfma_bf16_dense_takes_w4(M, 3 * U, U, U, 3 * U, 0, ws, p->qkv_b, nullptr) &&
+         mfma_bf16_dense_takes_w4(M, U, U, U, U, U, ws, p->proj_b, ws) &&
+         mfma_bf16_dense_takes_w4(M, F, U, U, F, 0, ws, p->ffn.ffn1_b, nullptr) &&
+         mfma_bf16_dense_takes_w4(M, U, F, F, U, U, ws, p->ffn.ffn2_b, ws) && !c->pre_norm &&
+         p->ffn.gate_w == nullptr;
+}
+
 int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
   REQUIRE(c != nullptr, "cfg is NULL");
   REQUIRE(dtype_ok(c->dtype), "unsupported dtype %d", c->dtype);
@@ -481,6 +516,7 @@ extern "C" {
 
 int gnlp_version(void) { return 200; }
 int gnlp_attn_last_kernel(void) { return g_attn_kernel; }
+int gnlp_stack_last_packed(void) { return g_stack_packed; }
 void gnlp_reload_knobs(void) { reload_knobs(); }
 const char *gnlp_last_error(void) { return g_err.c_str(); }
 int gnlp_device_count(void) {
@@ -864,8 +900,10 @@ size_t gnlp_encoder_workspace_bytes(const gnlp_encoder_cfg *cfg, int64_t B, int6
                                     int want_weights) {
   if (!cfg || B < 0 || L < 0 || cfg->heads <= 0) return 0;
   // layer scratch + two ping-pong activations for the stack driver
+  // (+ the sequence offsets of a packed ragged batch: B + 2 int32)
   return enc_ws(cfg, B, L, want_weights != 0).total +
-         2 * align256((size_t)B * L * cfg->units * esize(cfg->dtype));
+         2 * align256((size_t)B * L * cfg->units * esize(cfg->dtype)) +
+         align256((size_t)(B + 2) * sizeof(int32_t));
 }
 
 int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_layer_params *p,
@@ -932,6 +970,38 @@ int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_laye
   char *base = (char *)workspace;
   void *pp[2] = {base + layer_bytes, base + layer_bytes + act_bytes};
   const void *in = x;
+  // Ragged batch whose padded rows come out as zeros anyway (final_seq_mask): run the layers on the
+  // valid tokens only -- gather, n layers on (sum vl) rows, scatter + zero fill.  Row by row the
+  // results are bit-identical to the padded run (no kernel mixes rows except attention, which sees
+  // the same keys).  Needs the persistent GEMM for all four shapes and the fused attention kernel.
+  const size_t cu_bytes = align256((size_t)(B + 2) * sizeof(int32_t));
+  g_stack_packed = 0;
+  if (valid_length && final_seq_mask && !all_encodings && knobs().pack_ragged &&
+      workspace_bytes >= layer_bytes + 2 * act_bytes + cu_bytes &&
+      stack_can_pack(cfg, B, L, base, layers)) {
+    hipStream_t s = S(stream);
+    g_stack_packed = 1;
+    int32_t *cu = (int32_t *)(base + layer_bytes + 2 * act_bytes);
+    launch_seq_offsets(cu, valid_length, vl_dtype, B, L, s);
+    launch_pack_rows(pp[1], x, cu, cfg->dtype, B, L, cfg->units, cfg->time_major, s);
+    // the context rows between the last token and the dense row count belong to no sequence: the
+    // attention kernel never writes them, the projection GEMM reads them (every layer: once is enough)
+    launch_zero_pad_rows(base + enc_ws(cfg, B, L, false).ctx, cu, cfg->dtype, B, cfg->units, s);
+    RowsDevScope scope(cu + B + 1);
+    in = pp[1];
+    for (int i = 0; i < n_layers; ++i) {
+      void *dst = pp[i & 1];
+      const gnlp_encoder_layer_params *p = &layers[i];
+      REQUIRE(p->qkv_w && p->proj_w && p->ln_g && p->ffn.ffn1_w && p->ffn.ffn2_w && p->ffn.ln_g,
+              "missing weights in layer %d", i);
+      rc = encoder_layer_impl(dst, in, p, cfg, B, L, nullptr, valid_length, vl_dtype, nullptr, 0,
+                              base, layer_bytes, s, cu);
+      if (rc) return rc;
+      in = dst;
+    }
+    launch_unpack_rows(out, in, cu, cfg->dtype, B, L, cfg->units, cfg->time_major, s);
+    return check_launch("gnlp_encoder_stack_forward (packed)");
+  }
   for (int i = 0; i < n_layers; ++i) {
     void *dst;
     if (all_encodings) dst = all_encodings[i];

@@ -71,11 +71,15 @@ attn_fwd_bf16_d64(FusedAttn a) {
     if (causal && q0 + 128 < kv_len) kv_len = q0 + 128;
   }
   const int64_t my_q = q0 + wave * 32 + r;  // this lane's query row
-  bf16 *const obase = (bf16 *)a.o + b * a.os[0] + h * a.os[1];
+  // packed ragged batch: sequence b starts at token row cu[b] (batch strides are then 0) and rows
+  // beyond its valid length belong to the next sequence: they are never written
+  const int64_t tok0 = a.cu ? (int64_t)a.cu[b] : 0;
+  const int64_t q_store = a.cu ? q_valid : a.Lq;
+  bf16 *const obase = (bf16 *)a.o + b * a.os[0] + h * a.os[1] + tok0 * a.os[2];
   const int ntiles = (int)((kv_len + KV_TILE - 1) / KV_TILE);
 
   if (q0 >= q_valid || ntiles == 0) {  // block-uniform: every query row of the block is padded
-    if (my_q < a.Lq) {
+    if (my_q < q_store) {
       bf16x4 z = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
 #pragma unroll
       for (int g = 0; g < 8; ++g)
@@ -86,15 +90,15 @@ attn_fwd_bf16_d64(FusedAttn a) {
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[my_q][16 s + 8 hh .. +8] ----
   const int64_t qrow = my_q < a.Lq ? my_q : a.Lq - 1;
-  const bf16 *qp = (const bf16 *)a.q + b * a.qs[0] + h * a.qs[1] + qrow * a.qs[2];
+  const bf16 *qp = (const bf16 *)a.q + b * a.qs[0] + h * a.qs[1] + (tok0 + qrow) * a.qs[2];
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s + 8 * hh);
 
   // ---- staging: each wave moves 2 K pieces and 2 V pieces (8 rows x 128 B each) per tile ----
   const int srow = lane >> 3, cpos = lane & 7;
-  const bf16 *kbase = (const bf16 *)a.k + b * a.ks[0] + h * a.ks[1];
-  const bf16 *vbase = (const bf16 *)a.v + b * a.vs[0] + h * a.vs[1];
+  const bf16 *kbase = (const bf16 *)a.k + b * a.ks[0] + h * a.ks[1] + tok0 * a.ks[2];
+  const bf16 *vbase = (const bf16 *)a.v + b * a.vs[0] + h * a.vs[1] + tok0 * a.vs[2];
   // Lane pointers of tile 0; a full tile adds a uniform offset (scalar ALU) -- the per-lane
   // 64-bit row * stride products cost 74 of the 248 vector-ALU issue slots per tile (PMC +
   // disassembly) -- only the last, partial tile recomputes clamped rows.
@@ -331,7 +335,7 @@ attn_fwd_bf16_d64(FusedAttn a) {
     const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(ow + row * 128 + (((2 * oc + 1) ^ (row & 15)) << 3));
     const bf16x8 o8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     const int64_t qq = q0 + wave * 32 + row;
-    if (qq < a.Lq) *reinterpret_cast<bf16x8 *>(obase + qq * a.os[2] + oc * 8) = o8;
+    if (qq < q_store) *reinterpret_cast<bf16x8 *>(obase + qq * a.os[2] + oc * 8) = o8;
   }
 }
 

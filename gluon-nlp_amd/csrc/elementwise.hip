@@ -121,6 +121,160 @@ void launch_sequence_mask(void *out, const void *x, const void *vl, int vl_dtype
 }
 
 // ------------------------------------------------------------------------------------------
+// ragged batches packed to their valid tokens (no counterpart in the reference, which computes
+// every dense op over the padding): the stack drivers gather the rows t < valid_length[b] of a
+// (B, L, C) / (L, B, C) activation into one (sum vl, C) matrix, run the layers on it -- the GEMMs
+// and norms read the row count from device memory, the attention kernel the sequence offsets --
+// and scatter the result back with exact zeros beyond valid_length (the npx.sequence_mask of
+// models/bert.py:311-312).  HBM-bound: one read + one write of the valid rows each way.
+// ------------------------------------------------------------------------------------------
+// cu[0..B] = exclusive prefix sum of clamp(vl, 0, L);  cu[B + 1] = rows the dense kernels process:
+// cu[B] + 64 (rows a K / V tile of the last sequence may touch) rounded up to 256, at most B * L.
+__global__ void __launch_bounds__(256)
+seq_offsets_kernel(int32_t *__restrict__ cu, const void *__restrict__ vl, int vl_dtype, int64_t B,
+                   int64_t L) {
+  __shared__ int64_t part[257];
+  const int tid = threadIdx.x;
+  const int64_t per = (B + 255) / 256;
+  const int64_t b0 = tid * per < B ? tid * per : B, b1 = (b0 + per < B) ? b0 + per : B;
+  auto len = [&](int64_t b) {
+    const int64_t n = load_len(vl, vl_dtype, b);
+    return n < 0 ? 0 : (n > L ? L : n);
+  };
+  int64_t sum = 0;
+  for (int64_t b = b0; b < b1; ++b) sum += len(b);
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int64_t v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    part[256] = run;
+  }
+  __syncthreads();
+  int64_t run = part[tid];
+  for (int64_t b = b0; b < b1; ++b) {
+    cu[b] = (int32_t)run;
+    run += len(b);
+  }
+  if (tid == 0) {
+    const int64_t tot = part[256];
+    cu[B] = (int32_t)tot;
+    const int64_t m = (tot + 64 + 255) / 256 * 256, cap = (B * L + 255) / 256 * 256;
+    cu[B + 1] = (int32_t)(m < cap ? m : cap);
+  }
+}
+
+// packed[r] = x[row(b, t)] for r = cu[b] + t < cu[B]; zeros for cu[B] <= r < cu[B + 1]
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(T *__restrict__ packed, const T *__restrict__ x, const int32_t *__restrict__ cu,
+                 int64_t B, int64_t L, int C, int time_major) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= cu[B + 1]) return;
+  T *dst = packed + r * C;
+  if (r >= cu[B]) {
+    V z;
+#pragma unroll
+    for (int q = 0; q < N; ++q) z[q] = (T)0.0f;
+    for (int c = lane * N; c < C; c += 64 * N) *reinterpret_cast<V *>(dst + c) = z;
+    return;
+  }
+  int64_t lo = 0, hi = B;   // largest b with cu[b] <= r (wave-uniform)
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cu[mid] <= r) lo = mid; else hi = mid;
+  }
+  const int64_t t = r - cu[lo];
+  const T *src = x + (time_major ? t * B + lo : lo * L + t) * C;
+  for (int c = lane * N; c < C; c += 64 * N)
+    *reinterpret_cast<V *>(dst + c) = *reinterpret_cast<const V *>(src + c);
+}
+
+// out[row(b, t)] = t < vl[b] ? packed[cu[b] + t] : 0
+template <typename T>
+__global__ void __launch_bounds__(256)
+unpack_rows_kernel(T *__restrict__ out, const T *__restrict__ packed,
+                   const int32_t *__restrict__ cu, int64_t B, int64_t L, int C, int time_major) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * L) return;
+  const int64_t b = time_major ? row % B : row / L;
+  const int64_t t = time_major ? row / B : row % L;
+  T *dst = out + row * C;
+  if (t < cu[b + 1] - cu[b]) {
+    const T *src = packed + ((int64_t)cu[b] + t) * C;
+    for (int c = lane * N; c < C; c += 64 * N)
+      *reinterpret_cast<V *>(dst + c) = *reinterpret_cast<const V *>(src + c);
+  } else {
+    V z;
+#pragma unroll
+    for (int q = 0; q < N; ++q) z[q] = (T)0.0f;
+    for (int c = lane * N; c < C; c += 64 * N) *reinterpret_cast<V *>(dst + c) = z;
+  }
+}
+
+// zero the rows cu[B] .. cu[B + 1] - 1 (fewer than 320) of a packed (rows, C) buffer that no kernel
+// writes -- the attention context: no sequence owns them, the GEMM after it reads them
+template <typename T>
+__global__ void __launch_bounds__(256)
+zero_pad_rows_kernel(T *__restrict__ buf, const int32_t *__restrict__ cu, int64_t B, int C) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)cu[B] + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= cu[B + 1]) return;
+  V z;
+#pragma unroll
+  for (int q = 0; q < N; ++q) z[q] = (T)0.0f;
+  for (int c = lane * N; c < C; c += 64 * N) *reinterpret_cast<V *>(buf + r * C + c) = z;
+}
+
+void launch_zero_pad_rows(void *buf, const int32_t *cu, int dtype, int64_t B, int64_t C,
+                          hipStream_t s) {
+  if (dtype == GNLP_BF16)
+    zero_pad_rows_kernel<bf16><<<80, 256, 0, s>>>((bf16 *)buf, cu, B, (int)C);
+  else
+    zero_pad_rows_kernel<float><<<80, 256, 0, s>>>((float *)buf, cu, B, (int)C);
+}
+
+void launch_seq_offsets(int32_t *cu, const void *vl, int vl_dtype, int64_t B, int64_t L,
+                        hipStream_t s) {
+  seq_offsets_kernel<<<1, 256, 0, s>>>(cu, vl, vl_dtype, B, L);
+}
+
+// C a multiple of the 16-byte vector, tensors 16-byte aligned (checked by the caller)
+void launch_pack_rows(void *packed, const void *x, const int32_t *cu, int dtype, int64_t B,
+                      int64_t L, int64_t C, int time_major, hipStream_t s) {
+  const unsigned grid = (unsigned)((B * L + 255) / 256 * 256 / 4);
+  if (dtype == GNLP_BF16)
+    pack_rows_kernel<bf16><<<grid, 256, 0, s>>>((bf16 *)packed, (const bf16 *)x, cu, B, L, (int)C,
+                                                time_major);
+  else
+    pack_rows_kernel<float><<<grid, 256, 0, s>>>((float *)packed, (const float *)x, cu, B, L,
+                                                 (int)C, time_major);
+}
+
+void launch_unpack_rows(void *out, const void *packed, const int32_t *cu, int dtype, int64_t B,
+                        int64_t L, int64_t C, int time_major, hipStream_t s) {
+  const unsigned grid = (unsigned)((B * L + 3) / 4);
+  if (dtype == GNLP_BF16)
+    unpack_rows_kernel<bf16><<<grid, 256, 0, s>>>((bf16 *)out, (const bf16 *)packed, cu, B, L,
+                                                  (int)C, time_major);
+  else
+    unpack_rows_kernel<float><<<grid, 256, 0, s>>>((float *)out, (const float *)packed, cu, B, L,
+                                                   (int)C, time_major);
+}
+
+// ------------------------------------------------------------------------------------------
 // activations   (layers.py:236-338)
 // ------------------------------------------------------------------------------------------
 template <typename T, bool VEC>

@@ -215,6 +215,21 @@ bool mfma_dense_act_fused(int act) {
          act == GNLP_ACT_GELU_TANH;
 }
 
+static bool big_tiles(int64_t M, int64_t N) {
+  const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+  const Knobs &kn = knobs();   // developer knobs, read once per process (kernels.h)
+  // 256x256 tiles once they fill at least half of the 256 CUs (measured on T5-base, 192 tiles per
+  // GEMM: +25 % end to end over 768 tiles of 128x128)
+  return kn.gemm_tile ? (kn.gemm_tile == 256) : (t256 >= 128 && M >= 256 && N >= 256);
+}
+
+bool mfma_bf16_dense_takes_w4(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                              int64_t ldother, const void *out, const void *bias,
+                              const void *other) {
+  return big_tiles(M, N) && knobs().gemm_w4 &&
+         mfma_bf16_dense_w4_supported(M, N, K, ldx, ldo, ldother, out, bias, other);
+}
+
 void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void *bias,
                             const void *other, int combine, int act, int64_t M, int64_t N,
                             int64_t K, int64_t ldx, int64_t ldo, int64_t ldother, hipStream_t s) {
@@ -223,16 +238,11 @@ void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void 
   a.other = (const bf16 *)other; a.out = (bf16 *)out;
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.ldother = ldother;
   a.act = act; a.combine = combine; a.tiles_m = a.tiles_n = 0;
-  const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-  const Knobs &kn = knobs();   // developer knobs, read once per process (kernels.h)
-  // 256x256 tiles once they fill at least half of the 256 CUs (measured on T5-base, 192 tiles per
-  // GEMM: +25 % end to end over 768 tiles of 128x128)
-  const bool big = kn.gemm_tile ? (kn.gemm_tile == 256) : (t256 >= 128 && M >= 256 && N >= 256);
+  const bool big = big_tiles(M, N);
   // persistent, one wave per SIMD (gemm_bf16_w4.hip) when the shape allows; otherwise (ragged M / N,
   // N > 8192, or the developer knob GNLP_GEMM_W4=0) one 256x256 tile per workgroup with clamped
   // edges (gemm_bf16_pp.hip) -- same accumulation order and epilogue, bit-identical results
-  if (big && kn.gemm_w4 &&
-      mfma_bf16_dense_w4_supported(M, N, K, ldx, ldo, ldother, out, bias, other))
+  if (mfma_bf16_dense_takes_w4(M, N, K, ldx, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_w4(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
   else if (big && mfma_bf16_dense_pp_supported(N, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_pp(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);

@@ -70,6 +70,8 @@ struct DenseW4Args {
   bf16 *out;
   int64_t ldx, ldo, ldother;
   int K, nk, combine, tiles_m, tiles_n, group_m;
+  const int32_t *rows_dev;   // or null: the number of rows to process (a multiple of 256, at most
+                             // 256 * tiles_m) is read from device memory (packed ragged batches)
 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -155,7 +157,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- the tiles of this workgroup (XCD-aware band walk) ----
-  const int nt = a.tiles_m * a.tiles_n;
+  const int tiles_m = a.rows_dev ? (*a.rows_dev >> 8) : a.tiles_m;
+  const int nt = tiles_m * a.tiles_n;
   const int S = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int q8 = nt >> 3, r8 = nt & 7;
   const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -167,7 +170,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     const int GROUP_M = a.group_m;
     const int band = tile / (GROUP_M * a.tiles_n);
     const int band_m0 = band * GROUP_M;
-    const int band_h = (a.tiles_m - band_m0) < GROUP_M ? (a.tiles_m - band_m0) : GROUP_M;
+    const int band_h = (tiles_m - band_m0) < GROUP_M ? (tiles_m - band_m0) : GROUP_M;
     const int in_band = tile - band * GROUP_M * a.tiles_n;
     m0 = (band_m0 + in_band % band_h) * 256;
     n0 = (in_band / band_h) * NT;
@@ -570,6 +573,7 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   a.ldx = ldx; a.ldo = ldo; a.ldother = ldother;
   a.K = (int)K; a.nk = (int)(K >> 6); a.combine = combine;
   a.tiles_m = (int)(M / 256);
+  a.rows_dev = dense_rows_dev();
   const int width = w4_tile_width(M, N, w4_cu_count() & ~7);
   a.tiles_n = (int)(N / width);
   a.group_m = knobs().group_m;

@@ -35,6 +35,7 @@ struct Knobs {
   int gemm_nt;      // GNLP_GEMM_NT: 0 = by shape, 192 / 256 forced tile width
   bool norm_nt;     // GNLP_NORM_NT=0: plain instead of non-temporal loads in the norm kernel
   bool norm_full;   // GNLP_NORM_MAXV=f: always the full-width register image
+  bool pack_ragged; // GNLP_PACK_RAGGED=0: the stack drivers never pack a ragged batch
 };
 const Knobs &knobs();
 void reload_knobs();
@@ -156,12 +157,31 @@ struct FusedAttn {
   const void *vl;                       // or null (predicate i<vl && j<vl)
   int vl_dtype;
   int causal;                           // mask null: predicate (j <= i) && (i < vl) instead
+  const int32_t *cu;                    // or null; packed ragged batch: sequence b holds token rows
+                                        // cu[b] .. cu[b] + vl[b] - 1 (vl required, batch strides 0)
   const void *bias;                     // edge scores (bf16) or null
   int64_t bs[4];                        // (b, h, i, j)
   float inv_temperature;
 };
 bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv);
 void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s);
+
+// Ragged batches packed to their valid tokens (elementwise.hip): sequence offsets, gather, scatter.
+void launch_seq_offsets(int32_t *cu, const void *vl, int vl_dtype, int64_t B, int64_t L,
+                        hipStream_t s);
+void launch_pack_rows(void *packed, const void *x, const int32_t *cu, int dtype, int64_t B,
+                      int64_t L, int64_t C, int time_major, hipStream_t s);
+void launch_unpack_rows(void *out, const void *packed, const int32_t *cu, int dtype, int64_t B,
+                        int64_t L, int64_t C, int time_major, hipStream_t s);
+void launch_zero_pad_rows(void *buf, const int32_t *cu, int dtype, int64_t B, int64_t C,
+                          hipStream_t s);
+// While a packed stack runs (api.hip sets it, per host thread), the persistent GEMM and the norm
+// kernels read the number of rows to process from this device word instead of the host-side M.
+const int32_t *dense_rows_dev();
+// whether launch_mfma_bf16_dense would take the persistent kernel (the only GEMM that reads it)
+bool mfma_bf16_dense_takes_w4(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
+                              int64_t ldother, const void *out, const void *bias,
+                              const void *other);
 
 // attn_gen.hip : general attention on the f32 matrix cores (float32 or bf16 tensors, head dims
 // <= 128, optional `scores` / `attn_weights` outputs); no workspace

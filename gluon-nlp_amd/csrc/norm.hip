@@ -18,12 +18,13 @@ __global__ void __launch_bounds__(256)
 norm_vec_kernel(T *__restrict__ out, const T *__restrict__ x, const T *__restrict__ residual,
                 const T *__restrict__ gamma, const T *__restrict__ beta, int kind, float eps,
                 int64_t rows, int C, const void *__restrict__ vl, int vl_dtype, int64_t B,
-                int64_t L, int time_major) {
+                int64_t L, int time_major, const int32_t *__restrict__ rows_dev) {
   typedef typename VecOf<T>::type V;
   constexpr int N = VecOf<T>::N;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (rows_dev && row >= *rows_dev) return;   // packed ragged batch: rows past the valid tokens
   const int nvec = C / N;  // vectors per row
   T *orow = out + row * (int64_t)C;
   if (vl) {
@@ -113,10 +114,11 @@ __global__ void __launch_bounds__(256)
 norm_scalar_kernel(T *__restrict__ out, const T *__restrict__ x, const T *__restrict__ residual,
                    const T *__restrict__ gamma, const T *__restrict__ beta, int kind, float eps,
                    int64_t rows, int64_t C, const void *__restrict__ vl, int vl_dtype, int64_t B,
-                   int64_t L, int time_major) {
+                   int64_t L, int time_major, const int32_t *__restrict__ rows_dev) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (rows_dev && row >= *rows_dev) return;
   T *orow = out + row * C;
   if (vl) {
     const int64_t b = time_major ? row % B : row / L;
@@ -172,7 +174,8 @@ static void norm_t(void *out, const void *x, const void *residual, const void *g
 #define GNLP_NORM_LAUNCH(MV, NTV)                                                                \
   norm_vec_kernel<T, MV, NTV><<<grid, 256, 0, s>>>((T *)out, (const T *)x, (const T *)residual,  \
                                                    (const T *)gamma, (const T *)beta, kind, eps, \
-                                                   rows, (int)C, vl, vl_dtype, B, L, time_major)
+                                                   rows, (int)C, vl, vl_dtype, B, L, time_major, \
+                                                   dense_rows_dev())
     if (small && nt) GNLP_NORM_LAUNCH(MAXV / 2, true);
     else if (small) GNLP_NORM_LAUNCH(MAXV / 2, false);
     else if (nt) GNLP_NORM_LAUNCH(MAXV, true);
@@ -181,7 +184,7 @@ static void norm_t(void *out, const void *x, const void *residual, const void *g
   } else {
     norm_scalar_kernel<T><<<grid, 256, 0, s>>>((T *)out, (const T *)x, (const T *)residual,
                                                (const T *)gamma, (const T *)beta, kind, eps, rows,
-                                               C, vl, vl_dtype, B, L, time_major);
+                                               C, vl, vl_dtype, B, L, time_major, dense_rows_dev());
   }
 }
 

@@ -79,6 +79,7 @@ PROTOTYPES = {
     'gnlp_device_count': (c_int, []),
     'gnlp_reload_knobs': (None, []),
     'gnlp_attn_last_kernel': (c_int, []),
+    'gnlp_stack_last_packed': (c_int, []),
     'gnlp_gen_self_attn_mask': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int,
                                         c_void_p]),
     'gnlp_gen_mem_attn_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,

@@ -186,6 +186,17 @@ enum { GNLP_ATTN_KERNEL_NONE = 0, GNLP_ATTN_KERNEL_FUSED_BF16 = 1,
        GNLP_ATTN_KERNEL_GENERAL_MFMA = 2, GNLP_ATTN_KERNEL_UNFUSED = 3 };
 int gnlp_attn_last_kernel(void);
 
+/* Whether the last gnlp_encoder_stack_forward / gnlp_t5_encoder_forward call on THIS thread ran its
+ * ragged batch PACKED to the valid tokens (diagnostics and tests; no counterpart in the reference,
+ * which computes every dense op over the padding): with valid_length given, final_seq_mask set,
+ * bf16, layer shapes the persistent GEMM takes (B * L a multiple of 256, ...) and no
+ * all_encodings, the stack gathers the rows t < valid_length[b] into one (sum vl, units) matrix,
+ * runs the layers on it -- GEMMs and norms read the row count from device memory, the attention
+ * kernel the sequence offsets; nothing is synchronised with the host -- and scatters the result
+ * back with exact zeros beyond valid_length.  Row by row the results are bit-identical to the
+ * padded run.  GNLP_PACK_RAGGED=0 (developer knob) disables it. */
+int gnlp_stack_last_packed(void);
+
 int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, const void *q,
                              const void *k, const void *v, const gnlp_attn_desc *d, int dtype,
                              const uint8_t *mask, const int64_t mask_stride[3],
