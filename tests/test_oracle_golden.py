@@ -574,3 +574,42 @@ def test_l2_normalize_backward_by_finite_differences():
             xm[i, j] -= h
             num[i, j] = ((ref.l2_normalize(xp, -1, 1e-6) - ref.l2_normalize(xm, -1, 1e-6)) * go).sum() / (2 * h)
     assert_allclose(dx, num, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('method,bidirectional,max_distance', [
+    ('shaw', True, 3), ('shaw', False, 4), ('transformer_xl', False, None),
+    ('transformer_xl', True, 3)])
+def test_rel_attention_score_backward_by_finite_differences(method, bidirectional, max_distance):
+    """The reference holds no known answers for these gradients (its test compares gradient norms
+    across layouts, tests/test_attention_cell.py:313-391): central differences of the oracle's own
+    forward -- parity unpinned beyond that."""
+    rng = np.random.default_rng(0)
+    B, H, Lq, Lm, C = 2, 2, 4, 6, 3
+    q = rng.standard_normal((B, Lq, H, C))
+    rel = (np.arange(Lm)[None, :] - np.arange(Lq)[:, None]).astype(np.int32)
+    if method == 'shaw' and not bidirectional:
+        rel = np.abs(rel)
+    g = rng.standard_normal((B, H, Lq, Lm))
+    kw = dict(method=method, num_heads=H, max_distance=max_distance, bidirectional=bidirectional,
+              layout='NTK')
+    if method == 'shaw':
+        pname = 'shaw_weight'
+        w = rng.standard_normal(((2 * max_distance + 1) if bidirectional else max_distance + 1,
+                                 H * C))
+    else:
+        pname = 'rel_proj_weight'
+        w = rng.standard_normal((H * C, 6))
+    kw[pname] = w
+    dq, dp = ref.rel_attention_score_backward(g, q, rel, **kw)
+
+    def f(q_, w_):
+        return (ref.rel_attention_score(q_, rel, **{**kw, pname: w_}) * g).sum()
+    h = 1e-6
+    for arr, grad, which in ((q, dq, 0), (w, dp, 1)):
+        num = np.zeros_like(arr)
+        for idx in np.ndindex(arr.shape):
+            ap, am = arr.copy(), arr.copy()
+            ap[idx] += h
+            am[idx] -= h
+            num[idx] = ((f(ap, w) - f(am, w)) if which == 0 else (f(q, ap) - f(q, am))) / (2 * h)
+        assert_allclose(grad, num, rtol=1e-6, atol=1e-7)
