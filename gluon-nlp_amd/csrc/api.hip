@@ -844,6 +844,67 @@ int gnlp_rel_attn_score(void *out, const void *query, const int64_t *q_stride,
   return check_launch("gnlp_rel_attn_score");
 }
 
+int gnlp_rel_attn_score_backward(void *dq, const int64_t *dq_stride, float *d_pos_embed,
+                                 const void *grad_out, const void *query, const int64_t *q_stride,
+                                 const void *pos_embed, const int32_t *rel_positions, int dtype,
+                                 int64_t B, int64_t H, int64_t Lq, int64_t Lm, int64_t C, int64_t R,
+                                 int32_t clip_lo, int32_t clip_hi, int32_t base, int wrap,
+                                 gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "dtype=%d", dtype);
+  REQUIRE(B >= 0 && H >= 0 && Lq >= 0 && Lm >= 0 && C >= 0 && R >= 0, "negative extent");
+  hipStream_t s = S(stream);
+  if (d_pos_embed && R * H * C > 0) {
+    hipError_t e = hipMemsetAsync(d_pos_embed, 0, (size_t)(R * H * C) * sizeof(float), s);
+    if (e != hipSuccess) return fail(GNLP_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  if (B * H * Lq == 0) return GNLP_OK;
+  REQUIRE(grad_out && query && q_stride && pos_embed && rel_positions, "null argument");
+  REQUIRE(!dq || dq_stride, "dq given without strides");
+  REQUIRE(R >= 1, "empty position table (R=%lld)", (long long)R);
+  REQUIRE(clip_lo <= clip_hi, "clip range [%d, %d]", clip_lo, clip_hi);
+  REQUIRE(C <= 8192, "head units %lld > 8192", (long long)C);
+  REQUIRE(B * H * Lq <= 0x7fffffffLL, "B*H*Lq=%lld exceeds the grid limit", (long long)(B * H * Lq));
+  RelScoreArgs a;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lm = Lm; a.C = C; a.R = R;
+  for (int i = 0; i < 3; ++i) a.qs[i] = q_stride[i];
+  a.lo = clip_lo; a.hi = clip_hi; a.base = base; a.wrap = wrap ? 1 : 0;
+  launch_rel_score_bwd(dq, dq_stride, d_pos_embed, grad_out, query, pos_embed, rel_positions,
+                       dtype, a, s);
+  return check_launch("gnlp_rel_attn_score_backward");
+}
+
+int gnlp_bucket_embedding_backward(float *d_weight, const void *grad_out, const int32_t *rel,
+                                   int dtype, int64_t n, int64_t units, int bidirectional,
+                                   int num_buckets, int max_distance, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  BucketTable tb;
+  int rc = build_bucket_table(&tb, bidirectional, num_buckets, max_distance);
+  if (rc) return rc;
+  REQUIRE(n >= 0 && units >= 0, "negative extent");
+  hipStream_t s = S(stream);
+  if ((int64_t)num_buckets * units > 0) {
+    REQUIRE(d_weight, "NULL d_weight");
+    hipError_t e = hipMemsetAsync(d_weight, 0, (size_t)num_buckets * units * sizeof(float), s);
+    if (e != hipSuccess) return fail(GNLP_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  REQUIRE((grad_out && rel) || n * units == 0, "bad arguments");
+  launch_bucket_embedding_bwd(d_weight, grad_out, rel, dtype, n, units, tb, s);
+  return check_launch("gnlp_bucket_embedding_backward");
+}
+
+int gnlp_colsum(float *out, const void *x, int dtype, int64_t rows, int64_t C,
+                gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(rows >= 0 && C >= 0 && (out || C == 0) && (x || rows * C == 0), "bad arguments");
+  hipStream_t s = S(stream);
+  if (C > 0) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
+    if (e != hipSuccess) return fail(GNLP_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  launch_colsum(out, x, dtype, rows, C, s);
+  return check_launch("gnlp_colsum");
+}
+
 int gnlp_t5_rel_bias(void *out, const void *weight, int dtype, int64_t H, int64_t Lq, int64_t Lm,
                      int bidirectional, int num_buckets, int max_distance, gnlp_stream_t stream) {
   REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);

@@ -419,6 +419,29 @@ void launch_bucket_embedding(void *out, const void *weight, const int32_t *rel, 
                                                     units, tb);
 }
 
+// backward of bucket_embed_kernel: dweight[bucket(rel[i]), u] += g[i, u]  (fp32 atomics)
+template <typename T>
+__global__ void __launch_bounds__(256)
+bucket_embed_bwd_kernel(float *__restrict__ dweight, const T *__restrict__ g,
+                        const int32_t *__restrict__ rel, int64_t n, int64_t units,
+                        BucketTable tb) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * units) return;
+  const int64_t i = idx / units, u = idx % units;
+  atomicAdd(&dweight[(int64_t)bucket_of(rel[i], tb) * units + u], to_f32(g[idx]));
+}
+
+void launch_bucket_embedding_bwd(float *dweight, const void *g, const int32_t *rel, int dtype,
+                                 int64_t n, int64_t units, const BucketTable &tb, hipStream_t s) {
+  if (n * units == 0) return;
+  dim3 grid((unsigned)((n * units + 255) / 256));
+  if (dtype == GNLP_BF16)
+    bucket_embed_bwd_kernel<bf16><<<grid, 256, 0, s>>>(dweight, (const bf16 *)g, rel, n, units, tb);
+  else
+    bucket_embed_bwd_kernel<float><<<grid, 256, 0, s>>>(dweight, (const float *)g, rel, n, units,
+                                                        tb);
+}
+
 // out[h, i, j] = weight[bucket(j - i + rel0), h]; thread = one (h, i, j); j fastest => coalesced
 // stores, the (num_buckets, H) table stays in L1/L2.  (rel0 != 0: the one-row Toeplitz table.)
 template <typename T>

@@ -59,6 +59,12 @@ struct RelScoreArgs {
 };
 void launch_rel_score(void *out, const void *q, const void *emb, const int32_t *rel, int dtype,
                       const RelScoreArgs &a, hipStream_t s);
+void launch_rel_score_bwd(void *dq, const int64_t dq_stride[3], float *demb, const void *g,
+                          const void *q, const void *emb, const int32_t *rel, int dtype,
+                          const RelScoreArgs &a, hipStream_t s);
+void launch_bucket_embedding_bwd(float *dweight, const void *g, const int32_t *rel, int dtype,
+                                 int64_t n, int64_t units, const BucketTable &tb, hipStream_t s);
+void launch_colsum(float *out, const void *g, int dtype, int64_t rows, int64_t C, hipStream_t s);
 void launch_sinusoid(void *out, const float *pos, const float *base, int dtype, int64_t n,
                      int64_t units, hipStream_t s);
 

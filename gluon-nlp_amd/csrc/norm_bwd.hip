@@ -186,6 +186,18 @@ l2norm_bwd_kernel(T *__restrict__ dx, const T *__restrict__ g, const T *__restri
     dx[row * d + c] = from_f32<T>(to_f32(gr[c]) * inv - to_f32(xr[c]) * k2);
 }
 
+// column sums of a (rows, C) matrix: the bias gradient of a dense layer (fp32 atomics into a
+// zero-filled vector, one per column per workgroup)
+template <typename T>
+__global__ void __launch_bounds__(256)
+colsum_kernel(float *__restrict__ out, const T *__restrict__ g, int64_t rows, int64_t C) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.0f;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) acc += to_f32(g[r * C + c]);
+  atomicAdd(&out[c], acc);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 cast_f32_kernel(T *__restrict__ out, const float *__restrict__ in, int64_t n) {
@@ -218,6 +230,14 @@ void launch_l2_normalize_bwd(void *dx, const void *g, const void *x, int dtype, 
   else
     l2norm_bwd_kernel<float><<<grid, 256, 0, s>>>((float *)dx, (const float *)g,
                                                   (const float *)x, rows, d, eps);
+}
+
+void launch_colsum(float *out, const void *g, int dtype, int64_t rows, int64_t C, hipStream_t s) {
+  if (rows == 0 || C == 0) return;
+  const int64_t gy = rows < 256 ? rows : 256;
+  dim3 grid((unsigned)((C + 255) / 256), (unsigned)gy);
+  if (dtype == GNLP_BF16) colsum_kernel<bf16><<<grid, 256, 0, s>>>(out, (const bf16 *)g, rows, C);
+  else colsum_kernel<float><<<grid, 256, 0, s>>>(out, (const float *)g, rows, C);
 }
 
 void launch_cast_f32(void *out, int dtype, const float *in, int64_t n, hipStream_t s) {

@@ -116,6 +116,13 @@ PROTOTYPES = {
     'gnlp_l2_normalize_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                            c_float, c_void_p]),
     'gnlp_cast_from_f32': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    'gnlp_rel_attn_score_backward': (c_int, [c_void_p, POINTER(c_int64), c_void_p, c_void_p,
+                                             c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int,
+                                             c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                             c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'gnlp_bucket_embedding_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                               c_int64, c_int, c_int, c_int, c_void_p]),
+    'gnlp_colsum': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     'gnlp_gen_rel_position': (c_int, [c_void_p, c_int64, c_void_p]),
     'gnlp_relative_position_bucket': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                               c_void_p]),

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from . import _tensor as T
-from .autograd import AttnFn, wants_grad
+from .autograd import AttnFn, RelScoreFn, wants_grad
 from .op import l2_normalize
 
 __all__ = ['gen_self_attn_mask', 'gen_mem_attn_mask', 'masked_softmax', 'masked_logsoftmax',
@@ -447,7 +447,7 @@ class RelAttentionScoreCell(torch.nn.Module):
             lo, hi = (-self._max_distance if self._bidirectional else 0), self._max_distance
         if self._method == 'shaw':
             # the learned table itself: row = clipped position, negatives wrap (np.take 'wrap')
-            table, base, wrap = self._rel_pos_embed.weight.data, 0, int(self._bidirectional)
+            table, base, wrap = self._rel_pos_embed.weight, 0, int(self._bidirectional)
         else:
             # 'transformer_xl': project the sinusoids of every position in the (clipped) range
             if self._max_distance is not None:
@@ -463,10 +463,22 @@ class RelAttentionScoreCell(torch.nn.Module):
         if table.dtype != q.dtype:
             raise TypeError('query dtype {} != position embedding dtype {}'.format(q.dtype,
                                                                                   table.dtype))
-        table = table.contiguous()
-        out = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev)
-        _lib.check(_lib.load().gnlp_rel_attn_score(
-            T.ptr(out), T.ptr(q), (ctypes.c_int64 * 3)(*_bht_strides(q, self._layout)),
-            T.ptr(table), T.ptr(rel), T.code(q), B, H, Lq, Lm, self._head_query_units,
-            table.shape[0], lo, hi, base, wrap, T.stream(dev)))
+        qs = _bht_strides(q, self._layout)
+        C, R = self._head_query_units, table.shape[0]
+
+        def call(q, table):
+            table = table.contiguous()
+            out = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev)
+            _lib.check(_lib.load().gnlp_rel_attn_score(
+                T.ptr(out), T.ptr(q), (ctypes.c_int64 * 3)(*qs), T.ptr(table), T.ptr(rel),
+                T.code(q), B, H, Lq, Lm, C, R, lo, hi, base, wrap, T.stream(dev)))
+            return out
+
+        if wants_grad(q, table):
+            # gradients for the query and the cell's parameters (through the table: the learned
+            # 'shaw' embedding itself, or rel_proj's weight behind the sinusoids)
+            out = RelScoreFn.apply(q, table.contiguous(), rel,
+                                   (qs, B, H, Lq, Lm, C, lo, hi, base, wrap, self._layout), call)
+        else:
+            out = call(q, table)
         return T.like_caller(out, query)

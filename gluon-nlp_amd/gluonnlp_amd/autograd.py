@@ -159,3 +159,99 @@ class L2NormalizeFn(torch.autograd.Function):
             T.ptr(dx), T.ptr(g), T.ptr(x), T.code(x), x.numel() // max(d, 1), d, float(ctx.eps),
             T.stream(dev)))
         return dx, None, None
+
+
+class DenseFn(torch.autograd.Function):
+    """Plain ``Dense`` (identity activation, no fused operand): y = x W^T + b.
+    dx = g W and dW = g^T x are gnlp_dense calls on transposed operands (the transposes are torch
+    copies: plumbing), db = column sums of g (gnlp_colsum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, call):
+        ctx.save_for_backward(x, weight)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        return call(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, w = ctx.saved_tensors
+        dev = x.device
+        lib = _lib.load()
+        N, K = w.shape
+        g2 = g_out.contiguous().reshape(-1, N)
+        x2 = x.contiguous().reshape(-1, K)
+        M = x2.shape[0]
+
+        def mm(a, bt):     # a (m, k) @ bt (n, k)^T -> (m, n) through gnlp_dense
+            m, k = a.shape
+            n = bt.shape[0]
+            out = torch.empty((m, n), dtype=a.dtype, device=dev)
+            _lib.check(lib.gnlp_dense(T.ptr(out), T.ptr(a), T.ptr(bt), None, None,
+                                      _lib.COMBINE_ADD, _lib.ACT['identity'], T.code(a), m, n, k,
+                                      k, n, n, T.stream(dev)))
+            return out
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = mm(g2, w.detach().t().contiguous()).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = mm(g2.t().contiguous(), x2.t().contiguous())
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
+            acc = torch.empty((N,), dtype=torch.float32, device=dev)
+            _lib.check(lib.gnlp_colsum(T.ptr(acc), T.ptr(g2), T.code(g2), M, N, T.stream(dev)))
+            db = _cast_from_f32(acc, ctx.bias_dtype, dev)
+        return dx, dw, db, None
+
+
+class BucketEmbedFn(torch.autograd.Function):
+    """BucketPositionalEmbedding: weight[bucket(rel)]; the gradient scatters onto the table."""
+
+    @staticmethod
+    def forward(ctx, weight, rel32, cfg, call):
+        ctx.rel32, ctx.cfg = rel32, cfg
+        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        return call(weight)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        dev = g_out.device
+        g = g_out.contiguous()
+        bidirectional, num_buckets, max_distance = ctx.cfg
+        units = ctx.wshape[1]
+        acc = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().gnlp_bucket_embedding_backward(
+            T.ptr(acc), T.ptr(g), T.ptr(ctx.rel32), T.code(g), ctx.rel32.numel(), units,
+            int(bidirectional), num_buckets, max_distance, T.stream(dev)))
+        return _cast_from_f32(acc, ctx.wdtype, dev), None, None, None
+
+
+class RelScoreFn(torch.autograd.Function):
+    """RelAttentionScoreCell 'transformer_xl' / 'shaw': <q[b, h, i], table[idx(rel[i, j]), h]>
+    with gradients for the query and the (R, H * C) table."""
+
+    @staticmethod
+    def forward(ctx, q, table, rel, args, call):
+        ctx.save_for_backward(q, table)
+        ctx.rel, ctx.args, ctx.args_layout = rel, args[:-1], args[-1]
+        return call(q, table)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        q, table = ctx.saved_tensors
+        dev = q.device
+        qs, B, H, Lq, Lm, C, lo, hi, base, wrap = ctx.args
+        g = g_out.contiguous()
+        dq = torch.empty_like(q, memory_format=torch.contiguous_format) \
+            if ctx.needs_input_grad[0] else None
+        dqs = None
+        if dq is not None:
+            from .attention_cell import _bht_strides
+            dqs = (ctypes.c_int64 * 3)(*_bht_strides(dq, ctx.args_layout))
+        dt = torch.empty(table.shape, dtype=torch.float32, device=dev) \
+            if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.load().gnlp_rel_attn_score_backward(
+            T.ptr(dq), dqs, T.ptr(dt), T.ptr(g), T.ptr(q), (ctypes.c_int64 * 3)(*qs),
+            T.ptr(table), T.ptr(ctx.rel), T.code(q), B, H, Lq, Lm, C, table.shape[0], lo, hi,
+            base, wrap, T.stream(dev)))
+        if dt is not None:
+            dt = _cast_from_f32(dt, table.dtype, dev)
+        return dq, dt, None, None, None

@@ -12,7 +12,7 @@ from torch import nn
 
 from . import _lib
 from . import _tensor as T
-from .autograd import NormFn, wants_grad
+from .autograd import BucketEmbedFn, DenseFn, NormFn, wants_grad
 
 __all__ = ['PositionwiseFFN', 'GELU', 'get_activation', 'get_norm_layer', 'RMSNorm', 'NoNorm',
            'LayerNorm', 'Dense', 'BucketPositionalEmbedding', 'IdentityActivation', 'Activation',
@@ -240,26 +240,39 @@ class Dense(nn.Module):
     def forward(self, x, other=None, combine='add', act=None, out=None):
         xt = T.as_tensor(x)
         ot = T.as_tensor(other)
-        w = self.weight.data
-        b = self.bias.data if self.bias is not None else None
+        w = self.weight
+        b = self.bias
         dev = T.require_device(xt, ot, w, b)
         if xt.dtype != w.dtype:
             raise TypeError('input dtype {} != weight dtype {}'.format(xt.dtype, w.dtype))
-        xt = xt.contiguous()
         K = xt.shape[-1]
         assert K == self._in_units, 'last axis {} != in_units {}'.format(K, self._in_units)
-        M = xt.numel() // max(K, 1)
         N = self._units
-        if out is None:
-            out = torch.empty(xt.shape[:-1] + (N,), dtype=xt.dtype, device=dev)
+        act = self._act if act is None else act
         if ot is not None:
             ot = ot.contiguous()
-        act = self._act if act is None else act
-        _lib.check(_lib.load().gnlp_dense(
-            T.ptr(out), T.ptr(xt), T.ptr(w), T.ptr(b), T.ptr(ot),
-            _lib.COMBINE_MUL if combine == 'mul' else _lib.COMBINE_ADD, _lib.ACT[act], T.code(xt),
-            M, N, K, K, N, N, T.stream(dev)))
-        return T.like_caller(out, x)
+
+        def call(xt, w, b, out=out):
+            xt = xt.contiguous()
+            M = xt.numel() // max(K, 1)
+            if out is None:
+                out = torch.empty(xt.shape[:-1] + (N,), dtype=xt.dtype, device=dev)
+            _lib.check(_lib.load().gnlp_dense(
+                T.ptr(out), T.ptr(xt), T.ptr(w), T.ptr(b), T.ptr(ot),
+                _lib.COMBINE_MUL if combine == 'mul' else _lib.COMBINE_ADD, _lib.ACT[act],
+                T.code(xt), M, N, K, K, N, N, T.stream(dev)))
+            return out
+
+        if wants_grad(xt, ot, w, b):
+            # training through the plain layer only: y = x W^T + b (autograd.DenseFn)
+            if ot is not None or act != 'identity' or out is not None:
+                raise NotImplementedError(
+                    'the backward pass of the fused Dense epilogues (activation / other / out=) '
+                    'is not built; differentiate the plain layer or run under torch.no_grad()')
+            res = DenseFn.apply(xt, w, b, call)
+        else:
+            res = call(xt, w, b)
+        return T.like_caller(res, x)
 
 
 # ------------------------------------------------------------------------------------------
@@ -437,13 +450,21 @@ class BucketPositionalEmbedding(nn.Module):
 
     def forward(self, relative_positions):
         rp = T.as_tensor(relative_positions)
-        w = self.weight.data
-        dev = T.require_device(rp, w)
+        dev = T.require_device(rp, self.weight)
         rp32 = rp.to(torch.int32).contiguous()
-        out = torch.empty(tuple(rp32.shape) + (self._units,), dtype=w.dtype, device=dev)
-        _lib.check(_lib.load().gnlp_bucket_embedding(
-            T.ptr(out), T.ptr(w), T.ptr(rp32), T.code(w), rp32.numel(), self._units,
-            int(self._bidirectional), self._num_buckets, self._max_distance, T.stream(dev)))
+
+        def call(w):
+            out = torch.empty(tuple(rp32.shape) + (self._units,), dtype=w.dtype, device=dev)
+            _lib.check(_lib.load().gnlp_bucket_embedding(
+                T.ptr(out), T.ptr(w), T.ptr(rp32), T.code(w), rp32.numel(), self._units,
+                int(self._bidirectional), self._num_buckets, self._max_distance, T.stream(dev)))
+            return out
+
+        if wants_grad(self.weight):
+            out = BucketEmbedFn.apply(self.weight, rp32, (self._bidirectional, self._num_buckets,
+                                                          self._max_distance), call)
+        else:
+            out = call(self.weight)
         return T.like_caller(out, relative_positions)
 
     def __repr__(self):

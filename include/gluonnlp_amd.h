@@ -255,6 +255,32 @@ int gnlp_norm_backward(void *dx, float *dgamma, float *dbeta, const void *grad_o
 int gnlp_l2_normalize_backward(void *dx, const void *grad_out, const void *x, int dtype,
                                int64_t rows, int64_t d, float eps, gnlp_stream_t stream);
 
+/* VJP of gnlp_rel_attn_score (RelAttentionScoreCell 'transformer_xl' / 'shaw',
+ * attention_cell.py:816-875; the gradients tests/test_attention_cell.py:313-391 takes): for
+ * grad_out (B, H, Lq, Lm) contiguous,
+ *   dq[b, h, i, :]            = sum_j grad_out[b, h, i, j] pos_embed[idx(i, j), h, :]
+ *   d_pos_embed[idx, h, :]   += grad_out[b, h, i, j] query[b, h, i, :]
+ * dq (tensor dtype, addressed with dq_stride like the query) or NULL; d_pos_embed (R, H, C) fp32 or
+ * NULL, zero-filled by the call, accumulated with fp32 atomics.  Everything else as in the forward. */
+int gnlp_rel_attn_score_backward(void *dq, const int64_t *dq_stride, float *d_pos_embed,
+                                 const void *grad_out, const void *query, const int64_t *q_stride,
+                                 const void *pos_embed, const int32_t *rel_positions, int dtype,
+                                 int64_t B, int64_t H, int64_t Lq, int64_t Lm, int64_t C, int64_t R,
+                                 int32_t clip_lo, int32_t clip_hi, int32_t base, int wrap,
+                                 gnlp_stream_t stream);
+
+/* VJP of gnlp_bucket_embedding (BucketPositionalEmbedding, layers.py:486-524):
+ * d_weight[bucket(rel[i]), :] += grad_out[i, :]; d_weight (num_buckets, units) fp32, zero-filled
+ * by the call. */
+int gnlp_bucket_embedding_backward(float *d_weight, const void *grad_out, const int32_t *rel,
+                                   int dtype, int64_t n, int64_t units, int bidirectional,
+                                   int num_buckets, int max_distance, gnlp_stream_t stream);
+
+/* out[c] = sum_r x[r, c], fp32 (zero-filled by the call): the bias gradient of a Dense layer.  Its
+ * other two gradients are gnlp_dense calls on transposed operands (dx = g W, dW = g^T x). */
+int gnlp_colsum(float *out, const void *x, int dtype, int64_t rows, int64_t C,
+                gnlp_stream_t stream);
+
 /* out[i] = (dtype) in[i]: the fp32 accumulators above -> a parameter's dtype.  No counterpart in
  * the reference (MXNet accumulates in the parameter dtype). */
 int gnlp_cast_from_f32(void *out, int dtype, const float *in, int64_t n, gnlp_stream_t stream);
