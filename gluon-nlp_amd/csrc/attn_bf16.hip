@@ -188,6 +188,26 @@ attn_fwd_bf16_d64(FusedAttn a) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.0f;
+      if (HAS_BIAS) {   // the accumulators START from the bias (attention_cell.py:453-455: added
+        // before the temperature): no add after the MFMAs, the loads fly under the K reads.
+        // Host guarantees unit key stride; loads may be unaligned.
+        const int64_t kb0 = (int64_t)tile * KV_TILE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int64_t j0 = kb0 + kb * 32 + g * 8 + hh * 4;
+            if (j0 + 4 <= a.Lm) {
+              bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(brow + j0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sacc[kb][g * 4 + e] = (float)b4[e];
+            } else if (j0 < a.Lm) {   // the last 1-3 keys of a row whose length is not a multiple of 4
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                if (j0 + e < a.Lm) sacc[kb][g * 4 + e] = (float)brow[j0 + e];
+            }
+          }
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -204,23 +224,6 @@ attn_fwd_bf16_d64(FusedAttn a) {
     // (causal: the tile's last key lies beyond the wave's first row -> some (i, j) have j > i)
     const bool tail = DENSE_MASK || !rows_all_ok || (kbase_idx + KV_TILE > kv_len) ||
                       (causal && kbase_idx + KV_TILE - 1 > q0 + wave * 32);
-    if (HAS_BIAS) {  // host guarantees unit key stride; loads may be unaligned
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int64_t j0 = kbase_idx + kb * 32 + g * 8 + hh * 4;
-          if (j0 + 4 <= a.Lm) {
-            bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(brow + j0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sacc[kb][g * 4 + e] += (float)b4[e];
-          } else if (j0 < a.Lm) {   // the last 1-3 keys of a row whose length is not a multiple of 4
-#pragma unroll
-            for (int e = 0; e < 3; ++e)
-              if (j0 + e < a.Lm) sacc[kb][g * 4 + e] += (float)brow[j0 + e];
-          }
-        }
-    }
     if (tail) {   // wave-uniform: only the tile straddling kv_len, dense masks, padded rows
       const int kv_rem = (int)(kv_len - kbase_idx);   // keys of this tile below kv_len
 #pragma unroll
