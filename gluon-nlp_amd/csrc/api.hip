@@ -217,7 +217,8 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
               const void *v, const gnlp_attn_desc *d, int dtype, const uint8_t *mask,
               const int64_t *ms, const void *vl, int vl_dtype, const void *edge, const int64_t *es,
               float temperature, void *ws, size_t ws_bytes, hipStream_t s,
-              const int32_t *cu = nullptr) {
+              const int32_t *cu = nullptr, const float *edge_f32 = nullptr) {
+  // edge_f32: a float32 copy of `edge` (same strides), used by the fused kernel when it applies
   if (d->B == 0 || d->H == 0 || d->Lq == 0) return GNLP_OK;
   const float inv_t = temperature > 0.0f ? 1.0f / temperature : 1.0f;
   FusedAttn fa;
@@ -229,6 +230,10 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     fa.causal = (!mask && d->causal) ? 1 : 0;
     fa.bias = edge;
     if (edge) for (int i = 0; i < 4; ++i) fa.bs[i] = es[i];
+    if (edge && edge_f32 && !mask && !fa.causal && (uintptr_t)edge_f32 % 4 == 0) {
+      fa.bias = edge_f32;   // the loads become the accumulator init: no bf16 -> f32 converts
+      fa.bias_f32 = 1;
+    }
     fa.inv_temperature = inv_t;
     launch_fused_attn_bf16(fa, s);
     g_attn_kernel = GNLP_ATTN_KERNEL_FUSED_BF16;
@@ -1117,7 +1122,9 @@ T5Ws t5_ws(const gnlp_t5_cfg *c, int64_t B, int64_t L) {
 
 size_t gnlp_t5_workspace_bytes(const gnlp_t5_cfg *cfg, int64_t B, int64_t L) {
   if (!cfg || B < 0 || L < 0) return 0;
-  return t5_ws(cfg, B, L).total + 2 * align256((size_t)B * L * cfg->d_model * esize(cfg->dtype));
+  // (+ a float32 copy of the (H, 2L - 1) Toeplitz bias table for the bf16 attention kernel)
+  return t5_ws(cfg, B, L).total + 2 * align256((size_t)B * L * cfg->d_model * esize(cfg->dtype)) +
+         align256((size_t)cfg->heads * (2 * L) * sizeof(float));
 }
 
 int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params *layers,
@@ -1148,6 +1155,16 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
   gnlp_ffn_cfg f = t5_ffn_cfg(cfg);
   const void *h = x;
   int rc;
+  // bf16 Toeplitz table: widened once per call so that the attention kernel's bias loads are its
+  // accumulator init (optional: only when the caller's workspace has the room)
+  const float *bias_f32 = nullptr;
+  const size_t tab_bytes = align256((size_t)H * (2 * L) * sizeof(float));
+  if (position_bias && cfg->bias_toeplitz && cfg->dtype == GNLP_BF16 &&
+      workspace_bytes >= w.total + 2 * act_bytes + tab_bytes) {
+    float *tab = (float *)(base + w.total + 2 * act_bytes);
+    launch_widen_bf16(tab, position_bias, H * (2 * L - 1), s);
+    bias_f32 = tab + (L - 1);
+  }
   for (int i = 0; i < n_layers; ++i) {
     const gnlp_t5_block_params *p = &layers[i];
     REQUIRE(p->attn_ln_g && (p->qkv_w || (p->q_w && p->k_w && p->v_w)) && p->proj_w && p->ffn.ffn1_w &&
@@ -1192,7 +1209,7 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
     rc = attn_impl(base + w.ctx, nullptr, nullptr, qkv, qkv + (size_t)inner * e,
                    qkv + (size_t)2 * inner * e, &ad, cfg->dtype, nullptr, nullptr, valid_length,
                    vl_dtype, bias0, bias0 ? estr : nullptr, 0.0f, base + w.ffn,
-                   w.total - w.ffn, s);
+                   w.total - w.ffn, s, nullptr, bias_f32);
     if (rc) return rc;
     // t5.py:550-551  hidden = hidden + proj(out)
     rc = dense_impl(base + w.h1, base + w.ctx, p->proj_w, nullptr, h, GNLP_COMBINE_ADD,

@@ -30,7 +30,7 @@ constexpr int KV_TILE = 64;
 constexpr int TILE_BYTES = KV_TILE * 128;   // 64 keys x 64 bf16
 constexpr float NEG_BIG = -1.0e30f;
 
-template <bool HAS_BIAS, bool DENSE_MASK, bool CAUSAL>
+template <bool HAS_BIAS, bool DENSE_MASK, bool CAUSAL, bool BIAS_F32 = false>
 __global__ void __launch_bounds__(256, 2)
 attn_fwd_bf16_d64(FusedAttn a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
@@ -162,8 +162,9 @@ attn_fwd_bf16_d64(FusedAttn a) {
   const bool rows_all_ok = __all(row_ok);
   constexpr float RESCALE_THR = 8.0f;
   const uint8_t *mrow = DENSE_MASK ? a.mask + b * a.ms[0] + qrow * a.ms[1] : nullptr;
-  const bf16 *brow = HAS_BIAS ? (const bf16 *)a.bias + b * a.bs[0] + h * a.bs[1] + qrow * a.bs[2]
-                              : nullptr;
+  const int64_t boff = HAS_BIAS ? b * a.bs[0] + h * a.bs[1] + qrow * a.bs[2] : 0;
+  const bf16 *brow = (HAS_BIAS && !BIAS_F32) ? (const bf16 *)a.bias + boff : nullptr;
+  const float *browf = (HAS_BIAS && BIAS_F32) ? (const float *)a.bias + boff : nullptr;
 
   stage(0, 0);
   __syncthreads();
@@ -197,7 +198,17 @@ attn_fwd_bf16_d64(FusedAttn a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int64_t j0 = kb0 + kb * 32 + g * 8 + hh * 4;
-            if (j0 + 4 <= a.Lm) {
+            if (BIAS_F32) {   // a float32 copy of the bias: the loads ARE the accumulator init
+              if (j0 + 4 <= a.Lm) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(browf + j0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc[kb][g * 4 + e] = b4[e];
+              } else if (j0 < a.Lm) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                  if (j0 + e < a.Lm) sacc[kb][g * 4 + e] = browf[j0 + e];
+              }
+            } else if (j0 + 4 <= a.Lm) {
               bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(brow + j0);
 #pragma unroll
               for (int e = 0; e < 4; ++e) sacc[kb][g * 4 + e] = (float)b4[e];
@@ -342,6 +353,14 @@ attn_fwd_bf16_d64(FusedAttn a) {
   }
 }
 
+__global__ void __launch_bounds__(256) widen_bf16_kernel(float *out, const bf16 *in, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+void launch_widen_bf16(float *out, const void *in, int64_t n, hipStream_t s) {
+  if (n > 0) widen_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(out, (const bf16 *)in, n);
+}
+
 bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv) {
   if (dk != 64 || dv != 64) return false;
   if (a.B < 1 || a.H < 1 || a.Lq < 1 || a.Lm < 1) return false;
@@ -357,7 +376,7 @@ bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv) {
   if (a.bias) {  // vector loads of 4 consecutive keys of the bias row: unit key stride; any row /
     // head / batch stride (the Toeplitz table of the T5 stack has row stride -1: its 8-byte loads
     // are unaligned, which global memory allows); the last 1-3 keys of a row are read one by one
-    if (a.bs[3] != 1 || (uintptr_t)a.bias % 2 != 0) return false;
+    if (a.bs[3] != 1 || (uintptr_t)a.bias % (a.bias_f32 ? 4 : 2) != 0) return false;
   }
   if ((uintptr_t)a.o % 16 != 0) return false;
   return true;
@@ -368,7 +387,8 @@ void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s) {
   // (the causal predicate is a template argument: as a run-time flag it cost the full-length
   // non-causal case 20 %: 102 -> 123 us per launch at the BERT-large shape)
   if (a.bias) {
-    if (a.mask) attn_fwd_bf16_d64<true, true, false><<<grid, 256, 0, s>>>(a);
+    if (a.bias_f32) attn_fwd_bf16_d64<true, false, false, true><<<grid, 256, 0, s>>>(a);
+    else if (a.mask) attn_fwd_bf16_d64<true, true, false><<<grid, 256, 0, s>>>(a);
     else if (a.causal) attn_fwd_bf16_d64<true, false, true><<<grid, 256, 0, s>>>(a);
     else attn_fwd_bf16_d64<true, false, false><<<grid, 256, 0, s>>>(a);
   } else {

@@ -167,8 +167,10 @@ struct FusedAttn {
                                         // cu[b] .. cu[b] + vl[b] - 1 (vl required, batch strides 0)
   const void *bias;                     // edge scores (bf16) or null
   int64_t bs[4];                        // (b, h, i, j)
+  int bias_f32;                         // bias holds float32 (no mask, not causal): the stack's copy
   float inv_temperature;
 };
+void launch_widen_bf16(float *out, const void *in, int64_t n, hipStream_t s);
 bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv);
 void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s);
 
