@@ -578,3 +578,38 @@ def test_packed_ragged_stack_matches_oracle(nlp):
     exp, _ = ref.bert_transformer(prep(x[sel], torch.bfloat16), vl[sel],
                                   [oracle_params(lp, torch.bfloat16) for lp in layers], H)
     assert rel_err(got[sel], exp) < 3e-2      # two bf16 layers end to end (sqrt(2) x 2e-2)
+
+
+@pytest.mark.parametrize('B,L,case', [(512, 64, 'mixed'), (128, 256, 'zeros'), (128, 256, 'full'),
+                                      (300, 128, 'mixed')])
+def test_packed_ragged_stack_edge_batches(nlp, B, L, case):
+    """More sequences than the offset kernel has threads (B = 512: several per thread), a batch of
+    nothing but empty sequences, a full batch, and B * L not a multiple of 256 (B = 300: the
+    padded path must run): packed == padded bit for bit, zeros beyond valid_length."""
+    from gluonnlp_amd import _lib
+    from gluonnlp_amd.models import BertTransformer
+    torch.manual_seed(B + L)
+    U, H, F = 256, 4, 1024
+    m = BertTransformer(units=U, hidden_size=F, num_layers=2, num_heads=H, dtype='bfloat16').cuda()
+    for p in m.parameters():
+        p.data.normal_(0, 0.05)
+    gen = torch.Generator(device='cuda').manual_seed(B)
+    x = torch.randn((B, L, U), device='cuda', generator=gen).to(torch.bfloat16)
+    if case == 'zeros':
+        vl = torch.zeros((B,), dtype=torch.int64, device='cuda')
+    elif case == 'full':
+        vl = torch.full((B,), L, dtype=torch.int64, device='cuda')
+    else:
+        vl = torch.randint(0, L + 1, (B,), device='cuda', generator=gen)
+    try:
+        _lib.set_knob('GNLP_PACK_RAGGED', '0')
+        want, _ = m(x, vl)
+    finally:
+        _lib.set_knob('GNLP_PACK_RAGGED', None)
+    got, _ = m(x, vl)
+    assert _lib.load().gnlp_stack_last_packed() == (1 if (B * L) % 256 == 0 else 0)
+    assert torch.equal(got, want)
+    live = torch.arange(L, device='cuda')[None, :] < vl[:, None]
+    if bool((~live).any()):
+        assert float(got[~live].float().abs().max()) == 0.0
+    assert torch.isfinite(got.float()).all()
