@@ -370,21 +370,21 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
             float v[8];
-            if (ACT == GNLP_ACT_GELU_ERF) {
+            // pairs throughout (v_pk_add_f32 / v_cvt_pk_bf16_f32): left to itself the compiler
+            // shuffles the identity epilogue through v_perm / v_alignbit (600 instead of 256
+            // vector-ALU instructions per tile)
 #pragma unroll
-              for (int e = 0; e < 4; e += 2) {
-                const f32x2 g0 =
-                    gelu_erf_fast2((f32x2){lo[q][it][e] + bv[e], lo[q][it][e + 1] + bv[e + 1]});
-                const f32x2 g1 = gelu_erf_fast2(
-                    (f32x2){hi[q][it][e] + bv[4 + e], hi[q][it][e + 1] + bv[5 + e]});
-                v[e] = g0[0]; v[e + 1] = g0[1]; v[4 + e] = g1[0]; v[5 + e] = g1[1];
+            for (int e = 0; e < 4; e += 2) {
+              f32x2 g0 = (f32x2){lo[q][it][e], lo[q][it][e + 1]} + (f32x2){bv[e], bv[e + 1]};
+              f32x2 g1 = (f32x2){hi[q][it][e], hi[q][it][e + 1]} + (f32x2){bv[4 + e], bv[5 + e]};
+              if (ACT == GNLP_ACT_GELU_ERF) {
+                g0 = gelu_erf_fast2(g0);
+                g1 = gelu_erf_fast2(g1);
+              } else if (ACT != GNLP_ACT_IDENTITY) {
+                g0 = (f32x2){apply_act<false>(g0[0], ACT), apply_act<false>(g0[1], ACT)};
+                g1 = (f32x2){apply_act<false>(g1[0], ACT), apply_act<false>(g1[1], ACT)};
               }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[e] = apply_act<false>(lo[q][it][e] + bv[e], ACT);
-                v[4 + e] = apply_act<false>(hi[q][it][e] + bv[4 + e], ACT);
-              }
+              v[e] = g0[0]; v[e + 1] = g0[1]; v[4 + e] = g1[0]; v[5 + e] = g1[1];
             }
             if (HAS_OTHER) {
               const bf16x8 o8 = ring[k % 3][q][it];
