@@ -341,3 +341,26 @@ def test_dense_mfma_layout_asymmetric(nlp):
         d.weight.data = to_dev(w, dtype)
         got = to_np(d(to_dev(x, dtype)))
         assert np.array_equal(got, x @ w.T)
+
+
+@pytest.mark.parametrize('M', [256, 32768])
+def test_dense_gelu_epilogue_wide_range(nlp, M):
+    """The bf16 GELU epilogue (sigmoid-polynomial form, x^2 saturated through the multiply's clamp
+    modifier) over pre-activations in [-30, 30], through the 128x128 kernel (M = 256) and the
+    persistent one (M = 32768): the erf GELU within bf16 resolution everywhere, exactly x for large
+    x and (-)0 for very negative x -- nothing turns over where the polynomial would."""
+    from gluonnlp_amd.layers import Dense
+    N = K = 256
+    d = Dense(N, K, dtype='bfloat16').cuda()
+    d.weight.data = torch.eye(N, device='cuda').to(torch.bfloat16)
+    d.bias.data.zero_()
+    vals = torch.linspace(-30.0, 30.0, N * 8, device='cuda').to(torch.bfloat16)
+    x = vals.reshape(8, N).repeat(M // 8, 1).contiguous()
+    y = d(x, act='gelu')
+    xo = to_np(x[:8])
+    exp = ref.activation(xo, 'gelu')
+    got = to_np(y[:8])
+    assert np.all(np.abs(got - exp) <= 4e-3 * np.abs(exp) + 3e-4)
+    assert np.all(got[xo > 9] == xo[xo > 9])
+    assert np.all(np.abs(got[xo < -9]) < 1e-10)
+    assert torch.equal(y[:8], y[-8:])
