@@ -491,18 +491,23 @@ int static_scratch(void **ptr) {
 // persistent kernel (the one that reads the row count from device memory) at the padded size, the
 // attention call takes the fused kernel, rows move as 16-byte vectors, offsets fit int32.
 bool stack_can_pack(const gnlp_encoder_cfg *c, int64_t B, int64_t L, const void *ws,
-                    const gnlp_encoder_layer_params *layers) {
+                    const gnlp_encoder_layer_params *layers, int n_layers) {
   const int64_t U = c->units, F = c->hidden, M = B * L;
   if (c->dtype != GNLP_BF16 || M % 256 != 0 || M >= ((int64_t)1 << 31) || U % 8 != 0) return false;
+  if (c->pre_norm) return false;   // (no stack with a final sequence mask is pre-norm)
   if (!stack_attn_fuses(c->dtype, B, c->heads, U / c->heads, 3 * U, U)) return false;
-  const gnlp_encoder_layer_params *p = &layers[0];
-  if (!p->qkv_b || !p->proj_b || !p->ffn.ffn1_b || !p->ffn.ffn2_b) return false;   // (any is fine;
-  // the alignment checks below only need representative pointers: workspace and parameter rows)
-  return mfma_bf16_dense_takes_w4(M, 3 * U, U, U, 3 * U, 0, ws, p->qkv_b, nullptr) &&
-         mfma_bf16_dense_takes_w4(M, U, U, U, U, U, ws, p->proj_b, ws) &&
-         mfma_bf16_dense_takes_w4(M, F, U, U, F, 0, ws, p->ffn.ffn1_b, nullptr) &&
-         mfma_bf16_dense_takes_w4(M, U, F, F, U, U, ws, p->ffn.ffn2_b, ws) && !c->pre_norm &&
-         p->ffn.gate_w == nullptr;
+  // activations live in the 256-byte aligned workspace (`ws` stands for all of them); the bias
+  // vectors are the only operands whose alignment differs from layer to layer
+  for (int i = 0; i < n_layers; ++i) {
+    const gnlp_encoder_layer_params *p = &layers[i];
+    if (p->ffn.gate_w) return false;
+    if (!mfma_bf16_dense_takes_w4(M, 3 * U, U, U, 3 * U, 0, ws, p->qkv_b, nullptr) ||
+        !mfma_bf16_dense_takes_w4(M, U, U, U, U, U, ws, p->proj_b, ws) ||
+        !mfma_bf16_dense_takes_w4(M, F, U, U, F, 0, ws, p->ffn.ffn1_b, nullptr) ||
+        !mfma_bf16_dense_takes_w4(M, U, F, F, U, U, ws, p->ffn.ffn2_b, ws))
+      return false;
+  }
+  return true;
 }
 
 int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
@@ -1044,7 +1049,7 @@ int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_laye
   g_stack_packed = 0;
   if (valid_length && final_seq_mask && !all_encodings && knobs().pack_ragged &&
       workspace_bytes >= layer_bytes + 2 * act_bytes + cu_bytes &&
-      stack_can_pack(cfg, B, L, base, layers)) {
+      stack_can_pack(cfg, B, L, base, layers, n_layers)) {
     hipStream_t s = S(stream);
     g_stack_packed = 1;
     int32_t *cu = (int32_t *)(base + layer_bytes + 2 * act_bytes);

@@ -141,6 +141,128 @@ norm_bwd_kernel(T *__restrict__ dx, float *__restrict__ dgamma, float *__restric
   }
 }
 
+// The same with 16-byte accesses (C a multiple of the vector, rows 16-byte aligned, C <= 64 * N *
+// MAXV): a lane owns MAXV vectors of N consecutive columns.  x, g are read once, dx written once;
+// non-temporal loads (nothing here is read again).
+template <typename T, int MAXV>
+__global__ void __launch_bounds__(256)
+norm_bwd_vec_kernel(T *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                    const T *__restrict__ g, const T *__restrict__ x,
+                    const T *__restrict__ residual, const T *__restrict__ gamma, int kind,
+                    float eps, int64_t rows, int C) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  extern __shared__ float acc_lds[];   // [2][C]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) acc_lds[c] = 0.0f;
+  __syncthreads();
+  const float invC = 1.0f / (float)C;
+  const int nvec = C / N;
+  float pg[MAXV][N], pb[MAXV][N], gam[MAXV][N];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      pg[i][q] = pb[i][q] = 0.0f;
+      gam[i][q] = vi < nvec ? to_f32(gamma[vi * N + q]) : 0.0f;
+    }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const T *xr = x + row * C, *gr = g + row * C;
+    const T *rr = residual ? residual + row * C : nullptr;
+    float v[MAXV][N], go[MAXV][N];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        const V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(xr + vi * N));
+        const V b = __builtin_nontemporal_load(reinterpret_cast<const V *>(gr + vi * N));
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          v[i][q] = to_f32(a[q]);
+          go[i][q] = to_f32(b[q]);
+        }
+        if (rr) {
+          const V r = __builtin_nontemporal_load(reinterpret_cast<const V *>(rr + vi * N));
+#pragma unroll
+          for (int q = 0; q < N; ++q) v[i][q] += to_f32(r[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) s += v[i][q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[i][q] = go[i][q] = 0.0f;
+      }
+    }
+    float mean = 0.0f, rstd = 1.0f;
+    if (kind == GNLP_NORM_LAYER) {
+      mean = wave_sum(s) * invC;
+      float ss = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nvec) {
+#pragma unroll
+          for (int q = 0; q < N; ++q) ss += (v[i][q] - mean) * (v[i][q] - mean);
+        }
+      rstd = 1.0f / sqrtf(wave_sum(ss) * invC + eps);
+    } else if (kind == GNLP_NORM_RMS) {
+      float ss = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int q = 0; q < N; ++q) ss += v[i][q] * v[i][q];
+      rstd = 1.0f / sqrtf(wave_sum(ss) * invC + eps);
+    }
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const bool in = lane + 64 * i < nvec;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        v[i][q] = in ? (v[i][q] - mean) * rstd : 0.0f;   // xh
+        pg[i][q] += go[i][q] * v[i][q];
+        pb[i][q] += go[i][q];
+        go[i][q] *= gam[i][q];                            // gg
+        s1 += go[i][q];
+        s2 += go[i][q] * v[i][q];
+      }
+    }
+    float m1 = 0.0f, m2 = 0.0f;
+    if (kind == GNLP_NORM_LAYER) m1 = wave_sum(s1) * invC;
+    if (kind != GNLP_NORM_NONE) m2 = wave_sum(s2) * invC;
+    T *dr = dx + row * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        V o;
+#pragma unroll
+        for (int q = 0; q < N; ++q) o[q] = from_f32<T>(rstd * (go[i][q] - m1 - v[i][q] * m2));
+        *reinterpret_cast<V *>(dr + vi * N) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nvec) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        atomicAdd(&acc_lds[vi * N + q], pg[i][q]);
+        atomicAdd(&acc_lds[C + vi * N + q], pb[i][q]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&dgamma[c], acc_lds[c]);
+    atomicAdd(&dbeta[c], acc_lds[C + c]);
+  }
+}
+
 template <typename T>
 void norm_bwd_t(void *dx, float *dgamma, float *dbeta, const void *g, const void *x,
                 const void *residual, const void *gamma, int kind, float eps, int64_t rows,
@@ -148,6 +270,20 @@ void norm_bwd_t(void *dx, float *dgamma, float *dbeta, const void *g, const void
   const int64_t want = (rows + 3) / 4;
   const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
   const size_t lds = (size_t)2 * C * sizeof(float);
+  constexpr int N = VecOf<T>::N;
+  const uintptr_t al = (uintptr_t)dx | (uintptr_t)g | (uintptr_t)x | (uintptr_t)(residual ? residual : x);
+  if (C % N == 0 && al % 16 == 0 && C / N <= 256) {   // at most 4 vectors per lane
+#define GNLP_NBV(MV)                                                                            \
+  norm_bwd_vec_kernel<T, MV><<<grid, 256, lds, s>>>((T *)dx, dgamma, dbeta, (const T *)g,       \
+                                                    (const T *)x, (const T *)residual,          \
+                                                    (const T *)gamma, kind, eps, rows, (int)C)
+    const int nvec = (int)(C / N);
+    if (nvec <= 64) GNLP_NBV(1);
+    else if (nvec <= 128) GNLP_NBV(2);
+    else GNLP_NBV(4);
+#undef GNLP_NBV
+    return;
+  }
 #define GNLP_NB(MAXE)                                                                          \
   norm_bwd_kernel<T, MAXE><<<grid, 256, lds, s>>>((T *)dx, dgamma, dbeta, (const T *)g,         \
                                                   (const T *)x, (const T *)residual,            \
