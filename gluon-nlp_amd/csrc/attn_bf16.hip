@@ -30,9 +30,17 @@ constexpr int KV_TILE = 64;
 constexpr int TILE_BYTES = KV_TILE * 128;   // 64 keys x 64 bf16
 constexpr float NEG_BIG = -1.0e30f;
 
+#ifdef ATTN_STAMP   // diagnostic build only (tools/attn_stamp.py): cycles and clock of a workgroup
+__device__ unsigned long long attn_dbg[4096 * 4];
+#endif
+
 template <bool HAS_BIAS, bool DENSE_MASK, bool CAUSAL, bool BIAS_F32 = false>
 __global__ void __launch_bounds__(256, 2)
 attn_fwd_bf16_d64(FusedAttn a) {
+#ifdef ATTN_STAMP
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -323,6 +331,17 @@ attn_fwd_bf16_d64(FusedAttn a) {
     cur ^= 1;
   }
 
+#ifdef ATTN_STAMP
+  if (threadIdx.x == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin < 4096) {
+      attn_dbg[lin * 4 + 0] = __builtin_amdgcn_s_memtime() - st_c0;
+      attn_dbg[lin * 4 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+      attn_dbg[lin * 4 + 2] = (unsigned long long)ntiles;
+      attn_dbg[lin * 4 + 3] = st_r0;
+    }
+  }
+#endif
   // ---- finalize: O / l.  A lane holds ctx[my_q][d*32 + 8 g + 4 hh .. +3]; the wave transposes its
   // 32 x 64 block through a private 4 KiB LDS image (8-byte slot index XOR (row & 15)) so that the
   // global stores are full 128-byte rows, 16 bytes per lane.
@@ -399,3 +418,9 @@ void launch_fused_attn_bf16(const FusedAttn &a, hipStream_t s) {
 }
 
 }  // namespace gnlp
+
+#ifdef ATTN_STAMP
+extern "C" int gnlp_debug_attn_read(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gnlp::attn_dbg), (size_t)n * sizeof(unsigned long long));
+}
+#endif
