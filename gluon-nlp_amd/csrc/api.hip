@@ -44,6 +44,7 @@ void reload_knobs() {
   k.gemm_nt = (nt == 192 || nt == 256) ? nt : 0;
   k.norm_nt = env_on("GNLP_NORM_NT");
   k.pack_ragged = env_on("GNLP_PACK_RAGGED");
+  k.attn_bwd_bf16 = env_on("GNLP_ATTN_BWD_BF16");
   const char *mv = getenv("GNLP_NORM_MAXV");
   k.norm_full = mv && mv[0] == 'f';
   g_knobs = k;

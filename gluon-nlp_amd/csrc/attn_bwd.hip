@@ -477,6 +477,10 @@ bool attn_bwd_supported(const GenAttnBwd &a) {
 
 void launch_attn_bwd(const GenAttnBwd &a, int dtype, hipStream_t s) {
   const int64_t dmax = a.dk > a.dv ? a.dk : a.dv;
+  if (dtype == GNLP_BF16 && knobs().attn_bwd_bf16 && attn_bwd_bf16_supported(a)) {
+    launch_attn_bwd_bf16(a, s);
+    return;
+  }
   if (dtype == GNLP_BF16) launch_bwd_t<bf16>(a, dmax, s);
   else launch_bwd_t<float>(a, dmax, s);
 }

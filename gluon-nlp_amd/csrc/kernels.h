@@ -36,6 +36,7 @@ struct Knobs {
   bool norm_nt;     // GNLP_NORM_NT=0: plain instead of non-temporal loads in the norm kernel
   bool norm_full;   // GNLP_NORM_MAXV=f: always the full-width register image
   bool pack_ragged; // GNLP_PACK_RAGGED=0: the stack drivers never pack a ragged batch
+  bool attn_bwd_bf16; // GNLP_ATTN_BWD_BF16=0: attention backward on the fp32 matrix cores for bf16 too
 };
 const Knobs &knobs();
 void reload_knobs();
@@ -231,6 +232,9 @@ struct GenAttnBwd {
 };
 bool attn_bwd_supported(const GenAttnBwd &a);
 void launch_attn_bwd(const GenAttnBwd &a, int dtype, hipStream_t s);
+// attn_bwd_bf16.hip: bf16 tensors with 64-wide heads on the bf16 matrix cores
+bool attn_bwd_bf16_supported(const GenAttnBwd &a);
+void launch_attn_bwd_bf16(const GenAttnBwd &a, hipStream_t s);
 
 // norm_bwd.hip
 constexpr int64_t kNormBwdMaxC = 8192;   // 2 * C fp32 LDS accumulators per workgroup
