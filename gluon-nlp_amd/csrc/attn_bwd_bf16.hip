@@ -2,15 +2,23 @@
 // bf16 matrix cores (v_mfma_f32_32x32x16_bf16) -- the shape the fused forward kernel of
 // attn_bf16.hip serves.  Same mathematics, work decomposition, masks and outputs as the general
 // kernels of attn_bwd.hip (read its header first); what differs:
-//   * Q, K, V, dO go through LDS as bf16: a row-major image ([64 rows][72]) for the products whose
-//     A operand runs along the head dimension (S^T = K Q^T, dP^T = V dO^T; S = Q K^T, dP = dO V^T)
-//     and a transposed image ([64 dims][72]) for those whose A operand runs along the sequence
-//     (dQ^T += K^T dS^T; dV^T += dO^T P, dK^T += Q^T dS); the B operands are registers;
+//   * Q, K, V, dO are staged in LDS as bf16 row-major images ([64 rows][72], 144-byte rows: the
+//     16-byte row reads of 16 consecutive rows fall in distinct banks); the global loads of the
+//     next tile are in flight (in registers) while the current one is multiplied; 53 KB of LDS
+//     per workgroup, two workgroups per CU;
+//   * products whose A operand runs along the head dimension (S^T = K Q^T, dP^T = V dO^T;
+//     S = Q K^T, dP = dO V^T) read 16-byte row fragments; those whose A operand runs along the
+//     sequence (dQ^T += K^T dS^T; dV^T += dO^T P, dK^T += Q^T dS) read the SAME image through the
+//     transposing ds_read_b64_tr_b16, as the forward kernel does for V;
 //   * P and dS, computed in fp32 from the fp32 accumulators, are rounded to bf16 to become the B
 //     operand of the second products (as the forward kernel does with P): accumulator registers
 //     8 s .. 8 s + 7 of a lane hold the keys (queries) {16 s + 4 hh + 0..3, 16 s + 8 + 4 hh + 0..3}
-//     of a 32-block, and the A fragment gathers the transposed image in that same order.
-// 16 x the matrix rate of the fp32 kernels: 6.9 ms -> see DESIGN.md at the BERT-large shape.
+//     of a 32-block, which is the order the transposing read delivers;
+//   * 32-blocks whose elements are all switched on (no bias, no dense mask, inside valid_length and
+//     below the causal diagonal) take a path without per-element predicates; statistics are kept
+//     in base-2 units (exp2 of one fused multiply-add); 1 / temperature is applied once to dQ / dK.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -19,8 +27,11 @@ namespace gnlp {
 namespace {
 
 constexpr float BB_NEG = -1.0e30f;
+constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int BT = 64;          // keys (kernel A) / queries (kernel B) per staged tile
-constexpr int LDW = 72;         // bf16 per image row: 64 + 8 pad (144 B, 16-byte aligned rows)
+constexpr int LDW = 72;         // bf16 per image row: 64 + 8 pad
+constexpr int IMG = BT * LDW;   // bf16 per image
+typedef __attribute__((address_space(3))) bf16x4 *lds_bf16x4_p;
 
 __device__ __forceinline__ void wave_lds_sync_bb() {
   __builtin_amdgcn_sched_barrier(0);
@@ -30,34 +41,38 @@ __device__ __forceinline__ void wave_lds_sync_bb() {
 }
 __device__ __forceinline__ int row_of_bb(int e, int hh) { return 8 * (e >> 2) + 4 * hh + (e & 3); }
 
-// rows r0 .. r0 + 63 of a (rows, 64) bf16 matrix with row stride `rs` -> row-major image `rm`
-// ([64][LDW]) and, if `tr`, transposed image ([64 dims][LDW]); rows >= nrows are zeros
-__device__ __forceinline__ void stage_tile(bf16 *rm, bf16 *tr, const bf16 *src, int64_t rs,
-                                           int64_t r0, int64_t nrows) {
-  for (int idx = threadIdx.x; idx < BT * 8; idx += blockDim.x) {
-    const int r = idx >> 3, c8 = idx & 7;
+// rows r0 .. r0 + 63 of a (rows, 64) bf16 matrix with row stride rs: 256 threads, two 16-byte
+// pieces each (rows tid / 8 and tid / 8 + 32); rows >= nrows are zeros
+__device__ __forceinline__ void tile_load(bf16x8 (&r)[2], const bf16 *src, int64_t rs, int64_t r0,
+                                          int64_t nrows) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int64_t row = r0 + (threadIdx.x >> 3) + 32 * u;
     bf16x8 v;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16)0.0f;
-    if (r0 + r < nrows) v = *reinterpret_cast<const bf16x8 *>(src + (r0 + r) * rs + c8 * 8);
-    if (rm) *reinterpret_cast<bf16x8 *>(rm + r * LDW + c8 * 8) = v;
-    if (tr) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) tr[(c8 * 8 + i) * LDW + r] = v[i];
-    }
+    if (row < nrows) v = *reinterpret_cast<const bf16x8 *>(src + row * rs + (threadIdx.x & 7) * 8);
+    r[u] = v;
   }
 }
-
-// A fragment from a row-major image: row blk * 32 + n, head dims 16 s + 8 hh .. + 7
-__device__ __forceinline__ bf16x8 frag_rm(const bf16 *rm, int blk, int n, int hh, int s) {
-  return *reinterpret_cast<const bf16x8 *>(rm + (blk * 32 + n) * LDW + 16 * s + 8 * hh);
+__device__ __forceinline__ void tile_store(bf16 *img, const bf16x8 (&r)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    *reinterpret_cast<bf16x8 *>(img + ((threadIdx.x >> 3) + 32 * u) * LDW + (threadIdx.x & 7) * 8) =
+        r[u];
 }
-// A fragment from a transposed image: dim, sequence positions blk * 32 + {16 s + 4 hh + 0..3,
-// 16 s + 8 + 4 hh + 0..3}
-__device__ __forceinline__ bf16x8 frag_tr(const bf16 *tr, int dim, int blk, int hh, int s) {
-  const bf16 *p = tr + dim * LDW + blk * 32 + 16 * s + 4 * hh;
-  const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p);
-  const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(p + 8);
+
+// A fragment along the head dimension: row blk * 32 + n, head dims 16 s + 8 hh .. + 7
+__device__ __forceinline__ bf16x8 frag_rm(const bf16 *img, int blk, int n, int hh, int s) {
+  return *reinterpret_cast<const bf16x8 *>(img + (blk * 32 + n) * LDW + 16 * s + 8 * hh);
+}
+// A fragment along the sequence: lane (n, hh) receives image[blk * 32 + {16 s + 4 hh + 0..3,
+// 16 s + 8 + 4 hh + 0..3}][d * 32 + n].  ds_read_b64_tr_b16: inside each group of 16 lanes, lane
+// i reads 4 bf16 of row (i >> 2) at columns 4 (i & 3) .. + 3 and receives column i of rows 0..3.
+__device__ __forceinline__ bf16x8 frag_tr(const bf16 *img, int blk, int d, int s, int tr_off) {
+  const bf16 *p = img + (blk * 32 + 16 * s) * LDW + d * 32 + tr_off;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_p)p);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_p)(p + 8 * LDW));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // accumulator registers 8 s .. 8 s + 7 -> the B operand of k-step s
@@ -67,27 +82,40 @@ __device__ __forceinline__ bf16x8 pack_b(const f32x16 &x, int s) {
   for (int i = 0; i < 8; ++i) b[i] = (bf16)x[8 * s + i];
   return b;
 }
+// bit e set iff 8 (e >> 2) + (e & 3) < t : the registers whose position inside the 32-block
+// (less the lane's 4 hh) lies below a per-lane limit
+__device__ __forceinline__ unsigned bits_below(int t) {
+  unsigned on = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    int c = t - 8 * g;
+    c = c < 0 ? 0 : (c > 4 ? 4 : c);
+    on |= ((1u << c) - 1u) << (4 * g);
+  }
+  return on;
+}
+
+typedef std::integral_constant<bool, true> full_t;
+typedef std::integral_constant<bool, false> part_t;
 
 // ------------------------------------------------------------------------------------------
-// kernel A: row statistics (lse, D) and dQ
+// kernel A: row statistics (lse in base-2 units, D) and dQ.  256 threads = 128 queries.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 attn_bwd_q_bf16_kernel(GenAttnBwd a) {
   extern __shared__ __attribute__((aligned(16))) char smem_bb[];
-  bf16 *Kr = (bf16 *)smem_bb;             // [64 keys][LDW]
-  bf16 *Vr = Kr + BT * LDW;               // [64 keys][LDW]
-  bf16 *Kt = Vr + BT * LDW;               // [64 dims][LDW]
-  const int nwaves = blockDim.x >> 6;
+  bf16 *img = (bf16 *)smem_bb;            // [K, V][IMG]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *Sw = (float *)(Kt + BT * LDW) + wave * (32 * 33);
+  float *Sw = (float *)(img + 2 * IMG) + wave * (32 * 33);
   const int n = lane & 31, hh = lane >> 5;
+  const int tr_off = (4 * hh + ((lane & 15) >> 2)) * LDW + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
 
-  const int64_t nqb = (a.Lq + 32 * nwaves - 1) / (32 * nwaves);
+  const int64_t nqb = (a.Lq + 127) / 128;
   const int64_t lin = blockIdx.x;
   const int64_t qb = lin % nqb;
   const int64_t h = (lin / nqb) % a.H, b = lin / (nqb * a.H);
-  const int64_t q0 = qb * 32 * nwaves + wave * 32;
+  const int64_t q0 = qb * 128 + wave * 32;
   const int64_t my_q = q0 + n;
   const bool wave_live = q0 < a.Lq;
 
@@ -101,7 +129,12 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
     vlen = load_len(a.vl, a.vl_dtype, b);
     vlen = vlen < 0 ? 0 : vlen;
   }
-  const bool row_on = vlen < 0 || my_q < vlen;
+  const bool gen = a.bias != nullptr || a.mask != nullptr;   // uniform: per-element bias / mask
+  // without a dense mask: key j of this lane's query is on iff j < klim
+  const int lim = (int)((vlen >= 0 && vlen < a.Lm) ? vlen : a.Lm);
+  int klim = 0;
+  if (my_q < a.Lq && (vlen < 0 || my_q < vlen))
+    klim = (a.causal && my_q + 1 < lim) ? (int)(my_q + 1) : lim;
 
   bf16x8 qf[4], gf[4];   // B operands: query my_q, head dims 16 s + 8 hh .. + 7
   {
@@ -113,7 +146,8 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
     }
   }
 
-  auto dot_blocks = [&](int kb, f32x16 &sacc, f32x16 &dpacc) {
+  // sacc[e] = <K[key(e)], Q[my_q]>,  dpacc[e] = <V[key(e)], dO[my_q]>
+  auto dot_blocks = [&](const bf16 *Kr, const bf16 *Vr, int kb, f32x16 &sacc, f32x16 &dpacc) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.0f;
 #pragma unroll
@@ -123,7 +157,9 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
     }
   };
 
-  auto bias_mask_block = [&](int64_t jb, f32x16 &sacc) -> unsigned {
+  // + bias; on-mask bits of the 16 registers (global accesses run along the key axis through
+  // the per-wave transpose image, as in attn_gen.hip)
+  auto bias_mask_block = [&](int jb, f32x16 &sacc) -> unsigned {
     if (a.bias) {
 #pragma unroll 2
       for (int it = 0; it < 16; ++it) {
@@ -138,128 +174,141 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
       for (int e = 0; e < 16; ++e) sacc[e] += Sw[n * 33 + row_of_bb(e, hh)];
       wave_lds_sync_bb();
     }
+    if (!a.mask) return bits_below(klim - jb - 4 * hh);
     unsigned on = 0;
-    if (a.mask) {
 #pragma unroll 2
-      for (int it = 0; it < 16; ++it) {
-        const int64_t i = q0 + 2 * it + hh, j = jb + n;
-        float mv = 0.0f;
-        if (i < a.Lq && j < a.Lm)
-          mv = a.mask[b * a.ms[0] + i * a.ms[1] + j * a.ms[2]] != 0 ? 1.0f : 0.0f;
-        Sw[(2 * it + hh) * 33 + n] = mv;
-      }
-      wave_lds_sync_bb();
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (Sw[n * 33 + row_of_bb(e, hh)] != 0.0f) on |= 1u << e;
-      wave_lds_sync_bb();
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t j = jb + row_of_bb(e, hh);
-        if (j < a.Lm && row_on && (vlen < 0 || j < vlen) && (!a.causal || j <= my_q)) on |= 1u << e;
-      }
+    for (int it = 0; it < 16; ++it) {
+      const int64_t i = q0 + 2 * it + hh, j = jb + n;
+      float mv = 0.0f;
+      if (i < a.Lq && j < a.Lm)
+        mv = a.mask[b * a.ms[0] + i * a.ms[1] + j * a.ms[2]] != 0 ? 1.0f : 0.0f;
+      Sw[(2 * it + hh) * 33 + n] = mv;
     }
+    wave_lds_sync_bb();
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (Sw[n * 33 + row_of_bb(e, hh)] != 0.0f) on |= 1u << e;
+    wave_lds_sync_bb();
     return on;
   };
 
   const float inv_t = a.inv_temperature;
-  int64_t kv_end = a.Lm;
-  if (a.causal && !a.mask) {
-    const int64_t qe = (qb + 1) * 32 * nwaves;
-    kv_end = qe < a.Lm ? qe : a.Lm;
-  }
-  if (vlen >= 0 && vlen < kv_end) kv_end = vlen;   // keys beyond valid_length are off for every row
+  const float c_scale = inv_t * LOG2E;   // > 0 (attn_bwd_bf16_supported)
+  // keys at or beyond kv_end are off for every row of the workgroup
+  int64_t kv_end = a.mask ? a.Lm : lim;
+  if (a.causal && !a.mask && (qb + 1) * 128 < kv_end) kv_end = (qb + 1) * 128;
   const int ntiles = (int)((kv_end + BT - 1) / BT);
 
-  // ---- pass 1 ----
-  float m_run = BB_NEG, l_run = 0.0f, d_run = 0.0f;
-  for (int t = 0; t < ntiles; ++t) {
+  // one sweep over the key tiles; body(Kr, Vr, kb, jb, full)
+  auto sweep = [&](auto &&body) {
+    if (ntiles == 0) return;
+    bf16x8 kreg[2], vreg[2];
+    tile_load(kreg, kg, a.ks[2], 0, a.Lm);
+    tile_load(vreg, vg, a.vs[2], 0, a.Lm);
+    __syncthreads();   // the previous sweep has left the images
+    tile_store(img, kreg);
+    tile_store(img + IMG, vreg);
     __syncthreads();
-    stage_tile(Kr, nullptr, kg, a.ks[2], (int64_t)t * BT, a.Lm);
-    stage_tile(Vr, nullptr, vg, a.vs[2], (int64_t)t * BT, a.Lm);
-    __syncthreads();
-    if (!wave_live) continue;
-#pragma unroll 1
-    for (int kb = 0; kb < BT / 32; ++kb) {
-      const int64_t jb = (int64_t)t * BT + kb * 32;
-      if (jb >= a.Lm) break;
-      f32x16 sacc, dpacc;
-      dot_blocks(kb, sacc, dpacc);
-      const unsigned on = bias_mask_block(jb, sacc);
-      float mloc = BB_NEG;
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (on & (1u << e)) mloc = fmaxf(mloc, sacc[e] * inv_t);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      if (mloc > m_run) {
-        const float alpha = __expf(m_run - mloc);
-        l_run *= alpha;
-        d_run *= alpha;
-        m_run = mloc;
+    const bf16 *Kr = img, *Vr = img + IMG;
+    for (int t = 0; t < ntiles; ++t) {
+      const bool more = t + 1 < ntiles;
+      if (more) {   // in flight under the products of tile t
+        tile_load(kreg, kg, a.ks[2], (int64_t)(t + 1) * BT, a.Lm);
+        tile_load(vreg, vg, a.vs[2], (int64_t)(t + 1) * BT, a.Lm);
       }
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (on & (1u << e)) {
-          const float w = __expf(sacc[e] * inv_t - m_run);
-          l_run += w;
-          d_run += w * dpacc[e];
+      if (wave_live) {
+#pragma unroll 1
+        for (int kb = 0; kb < BT / 32; ++kb) {
+          const int jb = t * BT + kb * 32;
+          if (jb >= kv_end) break;
+          if (!gen && __all(klim >= jb + 32)) body(Kr, Vr, kb, jb, full_t());
+          else body(Kr, Vr, kb, jb, part_t());
         }
+      }
+      if (more) {
+        __syncthreads();
+        tile_store(img, kreg);
+        tile_store(img + IMG, vreg);
+      }
+      __syncthreads();
     }
-  }
+  };
+
+  // ---- pass 1: m, l and sum_j exp(x_j - m) dP_j, rescaled together (base-2 units) ----
+  float m_run = BB_NEG, l_run = 0.0f, d_run = 0.0f;
+  sweep([&](const bf16 *Kr, const bf16 *Vr, int kb, int jb, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    f32x16 sacc, dpacc;
+    dot_blocks(Kr, Vr, kb, sacc, dpacc);
+    unsigned on = 0xffffu;
+    if (!FULL) on = gen ? bias_mask_block(jb, sacc) : bits_below(klim - jb - 4 * hh);
+    float mloc = BB_NEG;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (FULL || (on & (1u << e))) mloc = fmaxf(mloc, sacc[e]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mz = mloc > -1.0e29f ? mloc * c_scale : BB_NEG;
+    if (mz > m_run) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - mz);   // m_run = BB_NEG: both sums are 0
+      l_run *= alpha;
+      d_run *= alpha;
+      m_run = mz;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float w = __builtin_amdgcn_exp2f(fmaf(sacc[e], c_scale, -m_run));
+      if (!FULL) w = (on & (1u << e)) ? w : 0.0f;
+      l_run += w;
+      d_run = fmaf(w, dpacc[e], d_run);
+    }
+  });
   l_run += __shfl_xor(l_run, 32, 64);
   d_run += __shfl_xor(d_run, 32, 64);
   const bool any_on = l_run > 0.0f;
-  const float lse = any_on ? m_run + __logf(l_run) : 0.0f;
+  const float lse2 = any_on ? m_run + __builtin_amdgcn_logf(l_run) : 0.0f;   // fully masked: P = 0
   const float dsum = any_on ? d_run / l_run : 0.0f;
   if (wave_live && hh == 0 && my_q < a.Lq) {
     float *st = a.stats + ((b * a.H + h) * a.Lq + my_q) * 2;
-    st[0] = lse;
+    st[0] = lse2;
     st[1] = dsum;
   }
 
-  // ---- pass 2: dQ^T += K^T dS^T ----
+  // ---- pass 2: dQ^T += K^T dS^T (dS without the 1 / temperature) ----
   f32x16 dq[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[d][e] = 0.0f;
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();
-    stage_tile(Kr, Kt, kg, a.ks[2], (int64_t)t * BT, a.Lm);
-    stage_tile(Vr, nullptr, vg, a.vs[2], (int64_t)t * BT, a.Lm);
-    __syncthreads();
-    if (!wave_live) continue;
-#pragma unroll 1
-    for (int kb = 0; kb < BT / 32; ++kb) {
-      const int64_t jb = (int64_t)t * BT + kb * 32;
-      if (jb >= a.Lm) break;
-      f32x16 sacc, dpacc;
-      dot_blocks(kb, sacc, dpacc);
-      const unsigned on = bias_mask_block(jb, sacc);
-      f32x16 ds;
+  sweep([&](const bf16 *Kr, const bf16 *Vr, int kb, int jb, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    f32x16 sacc, dpacc;
+    dot_blocks(Kr, Vr, kb, sacc, dpacc);
+    unsigned on = 0xffffu;
+    if (!FULL) on = gen ? bias_mask_block(jb, sacc) : bits_below(klim - jb - 4 * hh);
+    f32x16 ds;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float p = (on & (1u << e)) ? __expf(sacc[e] * inv_t - lse) : 0.0f;
-        ds[e] = p * (dpacc[e] - dsum) * inv_t;
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 dsb = pack_b(ds, s);
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, d * 32 + n, kb, hh, s), dsb,
-                                                          dq[d], 0, 0, 0);
-      }
+    for (int e = 0; e < 16; ++e) {
+      float p = __builtin_amdgcn_exp2f(fmaf(sacc[e], c_scale, -lse2));
+      if (!FULL) p = (on & (1u << e)) ? p : 0.0f;
+      ds[e] = p * (dpacc[e] - dsum);
     }
-  }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 dsb = pack_b(ds, s);
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kr, kb, d, s, tr_off), dsb, dq[d],
+                                                        0, 0, 0);
+    }
+  });
   if (!wave_live) return;
 
+  // dq[d][e] = dQ[my_q][d * 32 + row_of(e)] * temperature
   bf16 *ob = (bf16 *)a.dq + b * a.dqs[0] + h * a.dqs[1];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Sw[n * 33 + row_of_bb(e, hh)] = dq[d][e];
+    for (int e = 0; e < 16; ++e) Sw[n * 33 + row_of_bb(e, hh)] = dq[d][e] * inv_t;
     wave_lds_sync_bb();
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
@@ -271,28 +320,24 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// kernel B: dK, dV, dE
+// kernel B: dK, dV, dE.  256 threads = 128 keys.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
   extern __shared__ __attribute__((aligned(16))) char smem_bb[];
-  bf16 *Qr = (bf16 *)smem_bb;             // [64 queries][LDW]
-  bf16 *Gr = Qr + BT * LDW;               // [64 queries][LDW]   (dO)
-  bf16 *Qt = Gr + BT * LDW;               // [64 dims][LDW]
-  bf16 *Gt = Qt + BT * LDW;               // [64 dims][LDW]
-  float *Ls = (float *)(Gt + BT * LDW);   // [64] lse
-  float *Ds = Ls + BT;                    // [64] D
-  const int nwaves = blockDim.x >> 6;
+  bf16 *img = (bf16 *)smem_bb;            // [Q, dO][IMG]
+  float *LD = (float *)(img + 2 * IMG);   // lse2[64], D[64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *Sw = Ds + BT + wave * (32 * 33);
+  float *Sw = LD + 2 * BT + wave * (32 * 33);
   const int n = lane & 31, hh = lane >> 5;
+  const int tr_off = (4 * hh + ((lane & 15) >> 2)) * LDW + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
 
-  const int64_t nkb = (a.Lm + 32 * nwaves - 1) / (32 * nwaves);
+  const int64_t nkb = (a.Lm + 127) / 128;
   const int64_t lin = blockIdx.x;
   const int64_t kbi = lin % nkb;
   const int64_t h = (lin / nkb) % a.H, b = lin / (nkb * a.H);
-  const int64_t k0 = kbi * 32 * nwaves + wave * 32;
+  const int64_t k0 = kbi * 128 + wave * 32;   // first key of this wave
   const int64_t my_k = k0 + n;
   const bool wave_live = k0 < a.Lm;
 
@@ -306,7 +351,12 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
     vlen = load_len(a.vl, a.vl_dtype, b);
     vlen = vlen < 0 ? 0 : vlen;
   }
+  const bool gen = a.bias != nullptr || a.mask != nullptr || a.de != nullptr;   // uniform
   const bool col_on = my_k < a.Lm && (vlen < 0 || my_k < vlen);
+  // without a dense mask: query i is on for this lane's key iff qlo <= i < qhi
+  const int qlim = (int)((vlen >= 0 && vlen < a.Lq) ? vlen : a.Lq);
+  const int qhi = col_on ? qlim : 0;
+  const int qlo = a.causal ? (int)my_k : 0;
 
   bf16x8 kf[4], vf[4];   // B operands: key my_k, head dims 16 s + 8 hh .. + 7
   {
@@ -325,79 +375,120 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
     for (int e = 0; e < 16; ++e) dk[d][e] = dv[d][e] = 0.0f;
 
   const float inv_t = a.inv_temperature;
-  int64_t q_end = a.Lq;
-  if (vlen >= 0 && vlen < q_end) q_end = vlen;   // query rows beyond valid_length are off
+  const float c_scale = inv_t * LOG2E;
+  const int64_t q_end = a.mask ? a.Lq : qlim;   // query rows beyond valid_length are off
   const int ntiles = (int)((q_end + BT - 1) / BT);
-  const int t0 = (a.causal && !a.mask) ? (int)((kbi * 32 * nwaves) / BT) : 0;
-  for (int t = t0; t < ntiles; ++t) {
-    __syncthreads();
-    stage_tile(Qr, Qt, qg, a.qs[2], (int64_t)t * BT, a.Lq);
-    stage_tile(Gr, Gt, gg, a.gs[2], (int64_t)t * BT, a.Lq);
-    for (int r = threadIdx.x; r < BT; r += blockDim.x) {
-      const int64_t i = (int64_t)t * BT + r;
-      float l = 0.0f, dd = 0.0f;
-      if (i < a.Lq) {
-        const float *st = a.stats + ((b * a.H + h) * a.Lq + i) * 2;
-        l = st[0];
-        dd = st[1];
-      }
-      Ls[r] = l;
-      Ds[r] = dd;
+  // causal predicate: query tiles that end before the workgroup's first key see none of its keys
+  const int t0 = (a.causal && !a.mask) ? (int)((kbi * 128) / BT) : 0;
+
+  auto block = [&](const bf16 *Qr, const bf16 *Gr, const float *Ls, const float *Ds, int qb, int ib,
+                   auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    // sacc[e] = <Q[query(e)], K[my_k]>,  dpacc[e] = <dO[query(e)], V[my_k]>
+    f32x16 sacc, dpacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Qr, qb, n, hh, s), kf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Gr, qb, n, hh, s), vf[s], dpacc, 0, 0, 0);
     }
-    __syncthreads();
-    if (!wave_live) continue;
-#pragma unroll 1
-    for (int qb = 0; qb < BT / 32; ++qb) {
-      const int64_t ib = (int64_t)t * BT + qb * 32;
-      if (ib >= a.Lq) break;
-      f32x16 sacc, dpacc;
+    f32x16 p, ds;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.0f;
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(Ls + qb * 32 + 8 * g + 4 * hh);
+      const f32x4 d4 = *reinterpret_cast<const f32x4 *>(Ds + qb * 32 + 8 * g + 4 * hh);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Qr, qb, n, hh, s), kf[s], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Gr, qb, n, hh, s), vf[s], dpacc, 0, 0, 0);
-      }
-      f32x16 p, ds;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = qb * 32 + row_of_bb(e, hh);
-        const int64_t i = (int64_t)t * BT + r;
-        bool on = col_on && i < a.Lq;
+      for (int c = 0; c < 4; ++c) {
+        const int e = 4 * g + c;
+        const int i = ib + 8 * g + 4 * hh + c;
         float x = sacc[e];
-        if (on) {
-          if (a.bias)
-            x += (float)((const bf16 *)a.bias)[b * a.bs[0] + h * a.bs[1] + i * a.bs[2] +
-                                                my_k * a.bs[3]];
-          if (a.mask) on = a.mask[b * a.ms[0] + i * a.ms[1] + my_k * a.ms[2]] != 0;
-          else on = (vlen < 0 || i < vlen) && (!a.causal || my_k <= i);
+        bool on = true;
+        if (!FULL) {
+          on = i >= qlo && i < qhi;
+          if (gen) {
+            on = col_on && i < a.Lq;
+            if (on) {
+              if (a.bias)
+                x += (float)((const bf16 *)a.bias)[b * a.bs[0] + h * a.bs[1] + i * a.bs[2] +
+                                                    my_k * a.bs[3]];
+              if (a.mask) on = a.mask[b * a.ms[0] + i * a.ms[1] + my_k * a.ms[2]] != 0;
+              else on = i >= qlo && i < qhi;
+            }
+          }
         }
-        p[e] = on ? __expf(x * inv_t - Ls[r]) : 0.0f;
-        ds[e] = p[e] * (dpacc[e] - Ds[r]) * inv_t;
-        if (a.de && on)
-          atomicAdd(a.de + b * a.des[0] + h * a.des[1] + i * a.des[2] + my_k * a.des[3], ds[e]);
+        float pe = __builtin_amdgcn_exp2f(fmaf(x, c_scale, -l4[c]));
+        if (!FULL) pe = on ? pe : 0.0f;
+        p[e] = pe;
+        ds[e] = pe * (dpacc[e] - d4[c]);
+        if (!FULL && a.de && on)
+          atomicAdd(a.de + b * a.des[0] + h * a.des[1] + i * a.des[2] + my_k * a.des[3],
+                    ds[e] * inv_t);
       }
+    }
+    // dV^T += dO^T P,  dK^T += Q^T dS
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 pb = pack_b(p, s), dsb = pack_b(ds, s);
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pb = pack_b(p, s), dsb = pack_b(ds, s);
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gt, d * 32 + n, qb, hh, s), pb,
-                                                          dv[d], 0, 0, 0);
-          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, d * 32 + n, qb, hh, s), dsb,
-                                                          dk[d], 0, 0, 0);
+      for (int d = 0; d < 2; ++d) {
+        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gr, qb, d, s, tr_off), pb, dv[d],
+                                                        0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qr, qb, d, s, tr_off), dsb, dk[d],
+                                                        0, 0, 0);
+      }
+    }
+  };
+
+  if (t0 < ntiles) {
+    bf16x8 qreg[2], greg[2];
+    float streg = 0.0f;
+    auto load = [&](int t) {
+      tile_load(qreg, qg, a.qs[2], (int64_t)t * BT, a.Lq);
+      tile_load(greg, gg, a.gs[2], (int64_t)t * BT, a.Lq);
+      if (threadIdx.x < 2 * BT) {   // threads 0..63: lse2, 64..127: D
+        const int64_t i = (int64_t)t * BT + (threadIdx.x & (BT - 1));
+        streg = i < a.Lq ? a.stats[((b * a.H + h) * a.Lq + i) * 2 + (threadIdx.x >> 6)] : 0.0f;
+      }
+    };
+    auto store = [&]() {
+      tile_store(img, qreg);
+      tile_store(img + IMG, greg);
+      if (threadIdx.x < 2 * BT) LD[threadIdx.x] = streg;
+    };
+    load(t0);
+    store();
+    __syncthreads();
+    const bf16 *Qr = img, *Gr = img + IMG;
+    const float *Ls = LD, *Ds = LD + BT;
+    for (int t = t0; t < ntiles; ++t) {
+      const bool more = t + 1 < ntiles;
+      if (more) load(t + 1);   // in flight under the products of tile t
+      if (wave_live) {
+#pragma unroll 1
+        for (int qb = 0; qb < BT / 32; ++qb) {
+          const int ib = t * BT + qb * 32;   // first query of the block
+          if (ib >= q_end) break;
+          if (!gen && __all(qlo <= ib && qhi >= ib + 32)) block(Qr, Gr, Ls, Ds, qb, ib, full_t());
+          else block(Qr, Gr, Ls, Ds, qb, ib, part_t());
         }
       }
+      if (more) {
+        __syncthreads();
+        store();
+      }
+      __syncthreads();
     }
   }
   if (!wave_live) return;
 
+  // dk[d][e] = dK[my_k][d * 32 + row_of(e)] * temperature,  dv[d][e] = dV[my_k][d * 32 + row_of(e)]
   bf16 *okb = (bf16 *)a.dk_out + b * a.dks[0] + h * a.dks[1];
   bf16 *ovb = (bf16 *)a.dv_out + b * a.dvs[0] + h * a.dvs[1];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Sw[n * 33 + row_of_bb(e, hh)] = dk[d][e];
+    for (int e = 0; e < 16; ++e) Sw[n * 33 + row_of_bb(e, hh)] = dk[d][e] * inv_t;
     wave_lds_sync_bb();
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
@@ -417,35 +508,33 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
   }
 }
 
+constexpr size_t kLdsQ = (size_t)2 * IMG * sizeof(bf16) + (size_t)4 * 32 * 33 * sizeof(float);
+constexpr size_t kLdsKV = kLdsQ + (size_t)2 * BT * sizeof(float);
+static_assert(kLdsKV <= 64 * 1024, "static LDS limit");
+
 }  // namespace
 
-// bf16, dk = dv = 64, 16-byte aligned rows (the vector loads of the staging and of the B operands)
+// bf16, dk = dv = 64, 16-byte aligned rows (the vector loads of the staging and of the B
+// operands), positive temperature (the running maximum is taken before scaling), sequence
+// lengths that fit the 32-bit position arithmetic
 bool attn_bwd_bf16_supported(const GenAttnBwd &a) {
   if (a.dk != 64 || a.dv != 64) return false;
   if (a.B < 1 || a.H < 1 || a.Lq < 1 || a.Lm < 1) return false;
+  if (a.Lq > (1 << 30) || a.Lm > (1 << 30)) return false;
+  if (!(a.inv_temperature > 0.0f)) return false;
   const int64_t *ss[4] = {a.qs, a.ks, a.vs, a.gs};
   for (int t = 0; t < 4; ++t)
     for (int e = 0; e < 3; ++e)
       if (ss[t][e] % 8 != 0) return false;
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.g) % 16 != 0) return false;
-  const int64_t nb = ((a.Lq > a.Lm ? a.Lq : a.Lm) + 31) / 32;
+  const int64_t nb = ((a.Lq > a.Lm ? a.Lq : a.Lm) + 127) / 128;
   return nb * a.H * a.B <= 0x7fffffffLL;
 }
 
 void launch_attn_bwd_bf16(const GenAttnBwd &a, hipStream_t s) {
-  {
-    const int nwaves = a.Lq <= 32 ? 1 : (a.Lq <= 64 ? 2 : 4);
-    const size_t lds = (size_t)3 * BT * LDW * sizeof(bf16) + (size_t)nwaves * 32 * 33 * sizeof(float);
-    const int64_t nqb = (a.Lq + 32 * nwaves - 1) / (32 * nwaves);
-    attn_bwd_q_bf16_kernel<<<dim3((unsigned)(nqb * a.H * a.B)), nwaves * 64, lds, s>>>(a);
-  }
-  {
-    const int nwaves = a.Lm <= 32 ? 1 : (a.Lm <= 64 ? 2 : 4);
-    const size_t lds = (size_t)4 * BT * LDW * sizeof(bf16) + 2 * BT * sizeof(float) +
-                       (size_t)nwaves * 32 * 33 * sizeof(float);
-    const int64_t nkb = (a.Lm + 32 * nwaves - 1) / (32 * nwaves);
-    attn_bwd_kv_bf16_kernel<<<dim3((unsigned)(nkb * a.H * a.B)), nwaves * 64, lds, s>>>(a);
-  }
+  const int64_t nqb = (a.Lq + 127) / 128, nkb = (a.Lm + 127) / 128;
+  attn_bwd_q_bf16_kernel<<<dim3((unsigned)(nqb * a.H * a.B)), 256, kLdsQ, s>>>(a);
+  attn_bwd_kv_bf16_kernel<<<dim3((unsigned)(nkb * a.H * a.B)), 256, kLdsKV, s>>>(a);
 }
 
 }  // namespace gnlp
