@@ -62,9 +62,9 @@ attn_bwd_q_kernel(GenAttnBwd a) {
   const int n = lane & 31, hh = lane >> 5;
 
   const int64_t nqb = (a.Lq + 32 * nwaves - 1) / (32 * nwaves);
-  const int64_t lin = blockIdx.x;
-  const int64_t qb = lin % nqb;
-  const int64_t h = (lin / nqb) % a.H, b = lin / (nqb * a.H);
+  int64_t head, qb;
+  xcd_head_map(blockIdx.x, nqb, a.B * a.H, head, qb);
+  const int64_t h = head % a.H, b = head / a.H;
   const int64_t q0 = qb * 32 * nwaves + wave * 32;
   const int64_t my_q = q0 + n;
   const bool wave_live = q0 < a.Lq;
@@ -287,9 +287,9 @@ attn_bwd_kv_kernel(GenAttnBwd a) {
   const int n = lane & 31, hh = lane >> 5;
 
   const int64_t nkb = (a.Lm + 32 * nwaves - 1) / (32 * nwaves);
-  const int64_t lin = blockIdx.x;
-  const int64_t kbi = lin % nkb;
-  const int64_t h = (lin / nkb) % a.H, b = lin / (nkb * a.H);
+  int64_t head, kbi;
+  xcd_head_map(blockIdx.x, nkb, a.B * a.H, head, kbi);
+  const int64_t h = head % a.H, b = head / a.H;
   const int64_t k0 = kbi * 32 * nwaves + wave * 32;   // first key of this wave
   const int64_t my_k = k0 + n;
   const bool wave_live = k0 < a.Lm;

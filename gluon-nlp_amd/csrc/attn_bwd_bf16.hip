@@ -2,10 +2,11 @@
 // bf16 matrix cores (v_mfma_f32_32x32x16_bf16) -- the shape the fused forward kernel of
 // attn_bf16.hip serves.  Same mathematics, work decomposition, masks and outputs as the general
 // kernels of attn_bwd.hip (read its header first); what differs:
-//   * Q, K, V, dO are staged in LDS as bf16 row-major images ([64 rows][72], 144-byte rows: the
-//     16-byte row reads of 16 consecutive rows fall in distinct banks); the global loads of the
-//     next tile are in flight (in registers) while the current one is multiplied; 53 KB of LDS
-//     per workgroup, two workgroups per CU;
+//   * Q, K, V, dO are staged in LDS as bf16 row-major images of 64 rows x 128 bytes by the
+//     global -> LDS DMA (no registers, no vector ALU), double-buffered: the next tile lands while
+//     the current one is multiplied, one barrier per tile.  The 16-byte chunk c of row r sits at
+//     chunk c ^ swz(r) (swz permutes bits 1..3 of r): both the 16-byte row reads of 16
+//     consecutive rows and the transposing reads below touch every bank once;
 //   * products whose A operand runs along the head dimension (S^T = K Q^T, dP^T = V dO^T;
 //     S = Q K^T, dP = dO V^T) read 16-byte row fragments; those whose A operand runs along the
 //     sequence (dQ^T += K^T dS^T; dV^T += dO^T P, dK^T += Q^T dS) read the SAME image through the
@@ -29,9 +30,9 @@ namespace {
 constexpr float BB_NEG = -1.0e30f;
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int BT = 64;          // keys (kernel A) / queries (kernel B) per staged tile
-constexpr int LDW = 72;         // bf16 per image row: 64 + 8 pad
-constexpr int IMG = BT * LDW;   // bf16 per image
-typedef __attribute__((address_space(3))) bf16x4 *lds_bf16x4_p;
+constexpr int IMGB = BT * 128;  // bytes per image
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
 
 __device__ __forceinline__ void wave_lds_sync_bb() {
   __builtin_amdgcn_sched_barrier(0);
@@ -41,38 +42,91 @@ __device__ __forceinline__ void wave_lds_sync_bb() {
 }
 __device__ __forceinline__ int row_of_bb(int e, int hh) { return 8 * (e >> 2) + 4 * hh + (e & 3); }
 
-// rows r0 .. r0 + 63 of a (rows, 64) bf16 matrix with row stride rs: 256 threads, two 16-byte
-// pieces each (rows tid / 8 and tid / 8 + 32); rows >= nrows are zeros
-__device__ __forceinline__ void tile_load(bf16x8 (&r)[2], const bf16 *src, int64_t rs, int64_t r0,
-                                          int64_t nrows) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int64_t row = r0 + (threadIdx.x >> 3) + 32 * u;
-    bf16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (bf16)0.0f;
-    if (row < nrows) v = *reinterpret_cast<const bf16x8 *>(src + row * rs + (threadIdx.x & 7) * 8);
-    r[u] = v;
-  }
-}
-__device__ __forceinline__ void tile_store(bf16 *img, const bf16x8 (&r)[2]) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-    *reinterpret_cast<bf16x8 *>(img + ((threadIdx.x >> 3) + 32 * u) * LDW + (threadIdx.x & 7) * 8) =
-        r[u];
+// chunk swizzle of image row r: bits (1, 2, 3) of r -> bits (2, 0, 1)
+__device__ __forceinline__ int swz(int r) {
+  return (((r >> 1) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 2) & 1);
 }
 
+// rows r0 .. r0 + 63 of a (rows, 64) bf16 matrix with row stride rs -> image: 4 waves, two
+// 1 KiB pieces (8 rows) each, 16 bytes per lane; rows >= nrows repeat row nrows - 1 (finite
+// values that only ever meet P = dS = 0).  A full tile costs no vector ALU: uniform tile base +
+// the lane's 32-bit element offset inside the tile.
+struct TileSrc {
+  const bf16 *src;
+  int64_t rs, nrows;
+  unsigned off[2];   // (row in tile) * rs + 8 * chunk for the lane's two pieces
+  bool small;        // 63 * rs + 56 fits 32 bits
+};
+__device__ __forceinline__ TileSrc tile_src(const bf16 *src, int64_t rs, int64_t nrows, int wave,
+                                            int lane) {
+  TileSrc t;
+  t.src = src;
+  t.rs = rs;
+  t.nrows = nrows;
+  t.small = rs >= 0 && rs < (1 << 24);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = (wave * 2 + u) * 8 + (lane >> 3);
+    t.off[u] = (unsigned)row * (unsigned)rs + 8u * (unsigned)((lane & 7) ^ swz(row));
+  }
+  return t;
+}
+__device__ __forceinline__ void tile_dma(char *img, const TileSrc &ts, int64_t r0, int wave,
+                                         int lane) {
+  if (ts.small && r0 + BT <= ts.nrows) {   // uniform
+    const bf16 *tb = ts.src + r0 * ts.rs;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds((gptr_t)(tb + (size_t)ts.off[u]),
+                                       (lptr_t)(img + (wave * 2 + u) * 1024), 16, 0, 0);
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int piece = wave * 2 + u;
+    const int row = piece * 8 + (lane >> 3);
+    int64_t gr = r0 + row;
+    gr = gr < ts.nrows ? gr : ts.nrows - 1;
+    const int chunk = (lane & 7) ^ swz(row);
+    __builtin_amdgcn_global_load_lds((gptr_t)(ts.src + gr * ts.rs + chunk * 8),
+                                     (lptr_t)(img + piece * 1024), 16, 0, 0);
+  }
+}
+
+// per-lane byte offsets of the fragment reads inside a 32-row block of an image
+struct FragOff {
+  int rm[4];      // row read: row n, chunk 2 s + hh
+  int tr[2][2];   // transposing read: [head-dim half d][rows + 8]
+};
+__device__ __forceinline__ FragOff frag_offsets(int lane) {
+  const int n = lane & 31, hh = lane >> 5;
+  FragOff f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) f.rm[s] = n * 128 + (((2 * s + hh) ^ swz(n)) << 4);
+  // ds_read_b64_tr_b16: inside each group of 16 lanes, lane i reads 4 bf16 of row (i >> 2) at
+  // columns 4 (i & 3) .. + 3 and receives column i of rows 0..3
+  const int q4 = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1;
+  const int base = (4 * hh + q4) * 128 + (p & 1) * 8;
+  const int c0 = (2 * g1 + (p >> 1)) ^ (((q4 >> 1) << 2) | hh);
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) f.tr[d][hi] = base + hi * 1024 + ((c0 ^ (4 * d) ^ (2 * hi)) << 4);
+  return f;
+}
 // A fragment along the head dimension: row blk * 32 + n, head dims 16 s + 8 hh .. + 7
-__device__ __forceinline__ bf16x8 frag_rm(const bf16 *img, int blk, int n, int hh, int s) {
-  return *reinterpret_cast<const bf16x8 *>(img + (blk * 32 + n) * LDW + 16 * s + 8 * hh);
+__device__ __forceinline__ bf16x8 frag_rm(const char *img, int blk, int s, const FragOff &f) {
+  return *reinterpret_cast<const bf16x8 *>(img + blk * 4096 + f.rm[s]);
 }
 // A fragment along the sequence: lane (n, hh) receives image[blk * 32 + {16 s + 4 hh + 0..3,
-// 16 s + 8 + 4 hh + 0..3}][d * 32 + n].  ds_read_b64_tr_b16: inside each group of 16 lanes, lane
-// i reads 4 bf16 of row (i >> 2) at columns 4 (i & 3) .. + 3 and receives column i of rows 0..3.
-__device__ __forceinline__ bf16x8 frag_tr(const bf16 *img, int blk, int d, int s, int tr_off) {
-  const bf16 *p = img + (blk * 32 + 16 * s) * LDW + d * 32 + tr_off;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_p)p);
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_p)(p + 8 * LDW));
+// 16 s + 8 + 4 hh + 0..3}][d * 32 + n].  (The compiler puts s_waitcnt vmcnt(0) in front of these
+// reads -- it cannot tell them from the LDS side of the DMA of the next tile; issuing them as
+// inline assembly removes the wait and changes nothing measurable: the tile has landed by then.)
+__device__ __forceinline__ bf16x8 frag_tr(const char *img, int blk, int d, int s, const FragOff &f) {
+  typedef __attribute__((address_space(3))) bf16x4 *lds_bf16x4_p;
+  const char *p = img + blk * 4096 + s * 2048;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_p)(p + f.tr[d][0]));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_p)(p + f.tr[d][1]));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // accumulator registers 8 s .. 8 s + 7 -> the B operand of k-step s
@@ -95,6 +149,37 @@ __device__ __forceinline__ unsigned bits_below(int t) {
   return on;
 }
 
+// acc[d][e] = X[r0 + n][d * 32 + row_of(e, hh)] / scale of this wave's 32 rows -> bf16 rows of
+// `out`: the wave transposes its 32 x 64 block through a private 4 KiB LDS image (8-byte slot
+// index XOR (row & 15)) so that the global stores are full 128-byte rows, 16 bytes per lane
+__device__ __forceinline__ void store_rows(char *ow, const f32x16 (&acc)[2], float scale, bf16 *out,
+                                           int64_t rs, int64_t r0, int64_t nrows, int lane) {
+  const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[d][g * 4 + e] * scale);
+      const int slot = d * 8 + g * 2 + hh;
+      *reinterpret_cast<bf16x4 *>(ow + n * 128 + ((slot ^ (n & 15)) << 3)) = o;
+    }
+  wave_lds_sync_bb();
+  const int oc = lane & 7, orow0 = lane >> 3;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + orow0;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(ow + row * 128 + (((2 * oc) ^ (row & 15)) << 3));
+    const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(ow + row * 128 + (((2 * oc + 1) ^ (row & 15)) << 3));
+    const int64_t rr = r0 + row;
+    if (rr < nrows)
+      *reinterpret_cast<bf16x8 *>(out + rr * rs + oc * 8) =
+          __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  wave_lds_sync_bb();
+}
+
 typedef std::integral_constant<bool, true> full_t;
 typedef std::integral_constant<bool, false> part_t;
 
@@ -104,17 +189,17 @@ typedef std::integral_constant<bool, false> part_t;
 __global__ void __launch_bounds__(256, 2)
 attn_bwd_q_bf16_kernel(GenAttnBwd a) {
   extern __shared__ __attribute__((aligned(16))) char smem_bb[];
-  bf16 *img = (bf16 *)smem_bb;            // [K, V][IMG]
+  char *img = smem_bb;                    // [2 buffers][K, V][IMGB]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *Sw = (float *)(img + 2 * IMG) + wave * (32 * 33);
+  float *Sw = (float *)(img + 4 * IMGB) + wave * (32 * 33);
   const int n = lane & 31, hh = lane >> 5;
-  const int tr_off = (4 * hh + ((lane & 15) >> 2)) * LDW + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+  const FragOff fo = frag_offsets(lane);
 
   const int64_t nqb = (a.Lq + 127) / 128;
-  const int64_t lin = blockIdx.x;
-  const int64_t qb = lin % nqb;
-  const int64_t h = (lin / nqb) % a.H, b = lin / (nqb * a.H);
+  int64_t head, qb;
+  xcd_head_map(blockIdx.x, nqb, a.B * a.H, head, qb);
+  const int64_t h = head % a.H, b = head / a.H;
   const int64_t q0 = qb * 128 + wave * 32;
   const int64_t my_q = q0 + n;
   const bool wave_live = q0 < a.Lq;
@@ -147,13 +232,13 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
   }
 
   // sacc[e] = <K[key(e)], Q[my_q]>,  dpacc[e] = <V[key(e)], dO[my_q]>
-  auto dot_blocks = [&](const bf16 *Kr, const bf16 *Vr, int kb, f32x16 &sacc, f32x16 &dpacc) {
+  auto dot_blocks = [&](const char *Kr, const char *Vr, int kb, f32x16 &sacc, f32x16 &dpacc) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Kr, kb, n, hh, s), qf[s], sacc, 0, 0, 0);
-      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Vr, kb, n, hh, s), gf[s], dpacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Kr, kb, s, fo), qf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Vr, kb, s, fo), gf[s], dpacc, 0, 0, 0);
     }
   };
 
@@ -199,23 +284,21 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
   if (a.causal && !a.mask && (qb + 1) * 128 < kv_end) kv_end = (qb + 1) * 128;
   const int ntiles = (int)((kv_end + BT - 1) / BT);
 
+  const TileSrc ksrc = tile_src(kg, a.ks[2], a.Lm, wave, lane);
+  const TileSrc vsrc = tile_src(vg, a.vs[2], a.Lm, wave, lane);
   // one sweep over the key tiles; body(Kr, Vr, kb, jb, full)
   auto sweep = [&](auto &&body) {
     if (ntiles == 0) return;
-    bf16x8 kreg[2], vreg[2];
-    tile_load(kreg, kg, a.ks[2], 0, a.Lm);
-    tile_load(vreg, vg, a.vs[2], 0, a.Lm);
-    __syncthreads();   // the previous sweep has left the images
-    tile_store(img, kreg);
-    tile_store(img + IMG, vreg);
+    tile_dma(img, ksrc, 0, wave, lane);
+    tile_dma(img + IMGB, vsrc, 0, wave, lane);
     __syncthreads();
-    const bf16 *Kr = img, *Vr = img + IMG;
+    int cur = 0;
     for (int t = 0; t < ntiles; ++t) {
-      const bool more = t + 1 < ntiles;
-      if (more) {   // in flight under the products of tile t
-        tile_load(kreg, kg, a.ks[2], (int64_t)(t + 1) * BT, a.Lm);
-        tile_load(vreg, vg, a.vs[2], (int64_t)(t + 1) * BT, a.Lm);
+      if (t + 1 < ntiles) {   // lands under the products of tile t
+        tile_dma(img + (cur ^ 1) * 2 * IMGB, ksrc, (int64_t)(t + 1) * BT, wave, lane);
+        tile_dma(img + (cur ^ 1) * 2 * IMGB + IMGB, vsrc, (int64_t)(t + 1) * BT, wave, lane);
       }
+      const char *Kr = img + cur * 2 * IMGB, *Vr = Kr + IMGB;
       if (wave_live) {
 #pragma unroll 1
         for (int kb = 0; kb < BT / 32; ++kb) {
@@ -225,18 +308,14 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
           else body(Kr, Vr, kb, jb, part_t());
         }
       }
-      if (more) {
-        __syncthreads();
-        tile_store(img, kreg);
-        tile_store(img + IMG, vreg);
-      }
       __syncthreads();
+      cur ^= 1;
     }
   };
 
   // ---- pass 1: m, l and sum_j exp(x_j - m) dP_j, rescaled together (base-2 units) ----
   float m_run = BB_NEG, l_run = 0.0f, d_run = 0.0f;
-  sweep([&](const bf16 *Kr, const bf16 *Vr, int kb, int jb, auto full_c) {
+  sweep([&](const char *Kr, const char *Vr, int kb, int jb, auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
     f32x16 sacc, dpacc;
     dot_blocks(Kr, Vr, kb, sacc, dpacc);
@@ -279,7 +358,7 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[d][e] = 0.0f;
-  sweep([&](const bf16 *Kr, const bf16 *Vr, int kb, int jb, auto full_c) {
+  sweep([&](const char *Kr, const char *Vr, int kb, int jb, auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
     f32x16 sacc, dpacc;
     dot_blocks(Kr, Vr, kb, sacc, dpacc);
@@ -297,26 +376,15 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
       const bf16x8 dsb = pack_b(ds, s);
 #pragma unroll
       for (int d = 0; d < 2; ++d)
-        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kr, kb, d, s, tr_off), dsb, dq[d],
+        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kr, kb, d, s, fo), dsb, dq[d],
                                                         0, 0, 0);
     }
   });
   if (!wave_live) return;
 
   // dq[d][e] = dQ[my_q][d * 32 + row_of(e)] * temperature
-  bf16 *ob = (bf16 *)a.dq + b * a.dqs[0] + h * a.dqs[1];
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Sw[n * 33 + row_of_bb(e, hh)] = dq[d][e] * inv_t;
-    wave_lds_sync_bb();
-#pragma unroll 2
-    for (int it = 0; it < 16; ++it) {
-      const int64_t i = q0 + 2 * it + hh;
-      if (i < a.Lq) ob[i * a.dqs[2] + d * 32 + n] = (bf16)Sw[(2 * it + hh) * 33 + n];
-    }
-    wave_lds_sync_bb();
-  }
+  store_rows((char *)Sw, dq, inv_t, (bf16 *)a.dq + b * a.dqs[0] + h * a.dqs[1], a.dqs[2], q0, a.Lq,
+             lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,18 +393,18 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
 __global__ void __launch_bounds__(256, 2)
 attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
   extern __shared__ __attribute__((aligned(16))) char smem_bb[];
-  bf16 *img = (bf16 *)smem_bb;            // [Q, dO][IMG]
-  float *LD = (float *)(img + 2 * IMG);   // lse2[64], D[64]
+  char *img = smem_bb;                    // [2 buffers][Q, dO][IMGB]
+  float *LD = (float *)(img + 4 * IMGB);  // [2 buffers][lse2[64], D[64]]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *Sw = LD + 2 * BT + wave * (32 * 33);
+  float *Sw = LD + 4 * BT + wave * (32 * 33);
   const int n = lane & 31, hh = lane >> 5;
-  const int tr_off = (4 * hh + ((lane & 15) >> 2)) * LDW + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+  const FragOff fo = frag_offsets(lane);
 
   const int64_t nkb = (a.Lm + 127) / 128;
-  const int64_t lin = blockIdx.x;
-  const int64_t kbi = lin % nkb;
-  const int64_t h = (lin / nkb) % a.H, b = lin / (nkb * a.H);
+  int64_t head, kbi;
+  xcd_head_map(blockIdx.x, nkb, a.B * a.H, head, kbi);
+  const int64_t h = head % a.H, b = head / a.H;
   const int64_t k0 = kbi * 128 + wave * 32;   // first key of this wave
   const int64_t my_k = k0 + n;
   const bool wave_live = k0 < a.Lm;
@@ -381,7 +449,7 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
   // causal predicate: query tiles that end before the workgroup's first key see none of its keys
   const int t0 = (a.causal && !a.mask) ? (int)((kbi * 128) / BT) : 0;
 
-  auto block = [&](const bf16 *Qr, const bf16 *Gr, const float *Ls, const float *Ds, int qb, int ib,
+  auto block = [&](const char *Qr, const char *Gr, const float *Ls, const float *Ds, int qb, int ib,
                    auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
     // sacc[e] = <Q[query(e)], K[my_k]>,  dpacc[e] = <dO[query(e)], V[my_k]>
@@ -390,8 +458,8 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
     for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Qr, qb, n, hh, s), kf[s], sacc, 0, 0, 0);
-      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Gr, qb, n, hh, s), vf[s], dpacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Qr, qb, s, fo), kf[s], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Gr, qb, s, fo), vf[s], dpacc, 0, 0, 0);
     }
     f32x16 p, ds;
 #pragma unroll
@@ -432,38 +500,44 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
       const bf16x8 pb = pack_b(p, s), dsb = pack_b(ds, s);
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gr, qb, d, s, tr_off), pb, dv[d],
+        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gr, qb, d, s, fo), pb, dv[d],
                                                         0, 0, 0);
-        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qr, qb, d, s, tr_off), dsb, dk[d],
+        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qr, qb, d, s, fo), dsb, dk[d],
                                                         0, 0, 0);
       }
     }
   };
 
   if (t0 < ntiles) {
-    bf16x8 qreg[2], greg[2];
     float streg = 0.0f;
-    auto load = [&](int t) {
-      tile_load(qreg, qg, a.qs[2], (int64_t)t * BT, a.Lq);
-      tile_load(greg, gg, a.gs[2], (int64_t)t * BT, a.Lq);
-      if (threadIdx.x < 2 * BT) {   // threads 0..63: lse2, 64..127: D
+    const TileSrc qsrc = tile_src(qg, a.qs[2], a.Lq, wave, lane);
+    const TileSrc gsrc = tile_src(gg, a.gs[2], a.Lq, wave, lane);
+    auto dma = [&](int buf, int t) {
+      tile_dma(img + buf * 2 * IMGB, qsrc, (int64_t)t * BT, wave, lane);
+      tile_dma(img + buf * 2 * IMGB + IMGB, gsrc, (int64_t)t * BT, wave, lane);
+    };
+    auto load_stats = [&](int t) {   // threads 0..63: lse2, 64..127: D
+      if (threadIdx.x < 2 * BT) {
         const int64_t i = (int64_t)t * BT + (threadIdx.x & (BT - 1));
         streg = i < a.Lq ? a.stats[((b * a.H + h) * a.Lq + i) * 2 + (threadIdx.x >> 6)] : 0.0f;
       }
     };
-    auto store = [&]() {
-      tile_store(img, qreg);
-      tile_store(img + IMG, greg);
-      if (threadIdx.x < 2 * BT) LD[threadIdx.x] = streg;
+    auto store_stats = [&](int buf) {
+      if (threadIdx.x < 2 * BT) LD[buf * 2 * BT + threadIdx.x] = streg;
     };
-    load(t0);
-    store();
+    dma(0, t0);
+    load_stats(t0);
+    store_stats(0);
     __syncthreads();
-    const bf16 *Qr = img, *Gr = img + IMG;
-    const float *Ls = LD, *Ds = LD + BT;
+    int cur = 0;
     for (int t = t0; t < ntiles; ++t) {
       const bool more = t + 1 < ntiles;
-      if (more) load(t + 1);   // in flight under the products of tile t
+      if (more) {   // lands under the products of tile t
+        dma(cur ^ 1, t + 1);
+        load_stats(t + 1);
+      }
+      const char *Qr = img + cur * 2 * IMGB, *Gr = Qr + IMGB;
+      const float *Ls = LD + cur * 2 * BT, *Ds = Ls + BT;
       if (wave_live) {
 #pragma unroll 1
         for (int qb = 0; qb < BT / 32; ++qb) {
@@ -473,60 +547,40 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
           else block(Qr, Gr, Ls, Ds, qb, ib, part_t());
         }
       }
-      if (more) {
-        __syncthreads();
-        store();
-      }
+      if (more) store_stats(cur ^ 1);
       __syncthreads();
+      cur ^= 1;
     }
   }
   if (!wave_live) return;
 
   // dk[d][e] = dK[my_k][d * 32 + row_of(e)] * temperature,  dv[d][e] = dV[my_k][d * 32 + row_of(e)]
-  bf16 *okb = (bf16 *)a.dk_out + b * a.dks[0] + h * a.dks[1];
-  bf16 *ovb = (bf16 *)a.dv_out + b * a.dvs[0] + h * a.dvs[1];
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Sw[n * 33 + row_of_bb(e, hh)] = dk[d][e] * inv_t;
-    wave_lds_sync_bb();
-#pragma unroll 2
-    for (int it = 0; it < 16; ++it) {
-      const int64_t j = k0 + 2 * it + hh;
-      if (j < a.Lm) okb[j * a.dks[2] + d * 32 + n] = (bf16)Sw[(2 * it + hh) * 33 + n];
-    }
-    wave_lds_sync_bb();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Sw[n * 33 + row_of_bb(e, hh)] = dv[d][e];
-    wave_lds_sync_bb();
-#pragma unroll 2
-    for (int it = 0; it < 16; ++it) {
-      const int64_t j = k0 + 2 * it + hh;
-      if (j < a.Lm) ovb[j * a.dvs[2] + d * 32 + n] = (bf16)Sw[(2 * it + hh) * 33 + n];
-    }
-    wave_lds_sync_bb();
-  }
+  store_rows((char *)Sw, dk, inv_t, (bf16 *)a.dk_out + b * a.dks[0] + h * a.dks[1], a.dks[2], k0,
+             a.Lm, lane);
+  store_rows((char *)Sw, dv, 1.0f, (bf16 *)a.dv_out + b * a.dvs[0] + h * a.dvs[1], a.dvs[2], k0,
+             a.Lm, lane);
 }
 
-constexpr size_t kLdsQ = (size_t)2 * IMG * sizeof(bf16) + (size_t)4 * 32 * 33 * sizeof(float);
-constexpr size_t kLdsKV = kLdsQ + (size_t)2 * BT * sizeof(float);
+constexpr size_t kLdsQ = (size_t)4 * IMGB + (size_t)4 * 32 * 33 * sizeof(float);
+constexpr size_t kLdsKV = kLdsQ + (size_t)4 * BT * sizeof(float);
 static_assert(kLdsKV <= 64 * 1024, "static LDS limit");
 
 }  // namespace
 
-// bf16, dk = dv = 64, 16-byte aligned rows (the vector loads of the staging and of the B
-// operands), positive temperature (the running maximum is taken before scaling), sequence
+// bf16, dk = dv = 64, 16-byte aligned rows of the inputs and the outputs (16-byte accesses), positive temperature (the running maximum is taken before scaling), sequence
 // lengths that fit the 32-bit position arithmetic
 bool attn_bwd_bf16_supported(const GenAttnBwd &a) {
   if (a.dk != 64 || a.dv != 64) return false;
   if (a.B < 1 || a.H < 1 || a.Lq < 1 || a.Lm < 1) return false;
   if (a.Lq > (1 << 30) || a.Lm > (1 << 30)) return false;
   if (!(a.inv_temperature > 0.0f)) return false;
-  const int64_t *ss[4] = {a.qs, a.ks, a.vs, a.gs};
-  for (int t = 0; t < 4; ++t)
+  const int64_t *ss[7] = {a.qs, a.ks, a.vs, a.gs, a.dqs, a.dks, a.dvs};
+  for (int t = 0; t < 7; ++t)
     for (int e = 0; e < 3; ++e)
       if (ss[t][e] % 8 != 0) return false;
-  if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.g) % 16 != 0) return false;
+  if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.g | (uintptr_t)a.dq |
+       (uintptr_t)a.dk_out | (uintptr_t)a.dv_out) % 16 != 0)
+    return false;
   const int64_t nb = ((a.Lq > a.Lm ? a.Lq : a.Lm) + 127) / 128;
   return nb * a.H * a.B <= 0x7fffffffLL;
 }

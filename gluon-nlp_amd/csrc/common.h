@@ -38,6 +38,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Workgroups are placed on the 8 XCDs round-robin by dispatch order.  Linear workgroup id ->
+// (head = batch * H + h, block) such that the nblk blocks of one head share an XCD (one L2) and are
+// dispatched together: what they all read (K / V, or Q / dO) is fetched from HBM once instead of
+// once per block.  Bijective when the number of heads is a multiple of 8; plain order otherwise.
+__device__ __forceinline__ void xcd_head_map(int64_t lin, int64_t nblk, int64_t nheads,
+                                             int64_t &head, int64_t &blk) {
+  if ((nheads & 7) == 0) {
+    const int64_t grp = lin / (8 * nblk), i = lin - grp * 8 * nblk;
+    head = grp * 8 + (i & 7);
+    blk = i >> 3;
+  } else {
+    blk = lin % nblk;
+    head = lin / nblk;
+  }
+}
+
 __device__ __forceinline__ int64_t load_len(const void *p, int vl_dtype, int64_t i) {
   return vl_dtype == GNLP_I64 ? ((const int64_t *)p)[i] : (int64_t)((const int32_t *)p)[i];
 }

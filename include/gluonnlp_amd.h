@@ -225,7 +225,10 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
  *   element count.  The call zero-fills it and accumulates with fp32 atomics (the summation order
  *   over the broadcast axes is not fixed); cast with gnlp_cast_from_f32 if a bf16 copy is wanted.
  * workspace: gnlp_attn_backward_workspace_bytes(d) bytes (two fp32 per (b, h, query) row).
- * Head dims <= 128 (the general f32-MFMA kernels of attn_bwd.hip); larger: GNLP_ERR_UNSUPPORTED. */
+ * Head dims <= 128 (the general f32-MFMA kernels of attn_bwd.hip); larger: GNLP_ERR_UNSUPPORTED.
+ * bf16 tensors with d_k = d_v = 64 and 16-byte aligned rows run on the bf16 matrix cores
+ * (attn_bwd_bf16.hip: P and dS rounded to bf16 as operands, like P in the forward kernel);
+ * GNLP_ATTN_BWD_BF16=0 (developer knob) keeps them on the f32-MFMA kernels. */
 typedef struct {
   int64_t g_stride[3], dq_stride[3], dk_stride[3], dv_stride[3];
 } gnlp_attn_grad_desc;
