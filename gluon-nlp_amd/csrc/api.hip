@@ -218,8 +218,11 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
               const void *v, const gnlp_attn_desc *d, int dtype, const uint8_t *mask,
               const int64_t *ms, const void *vl, int vl_dtype, const void *edge, const int64_t *es,
               float temperature, void *ws, size_t ws_bytes, hipStream_t s,
-              const int32_t *cu = nullptr, const float *edge_f32 = nullptr) {
+              const int32_t *cu = nullptr, const float *edge_f32 = nullptr, float *lse = nullptr,
+              void *ctx_lo = nullptr) {
   // edge_f32: a float32 copy of `edge` (same strides), used by the fused kernel when it applies
+  // lse, ctx_lo: the fused kernel's row statistics and the residual of ctx's bf16 rounding, for
+  // the backward pass; no other kernel writes them
   if (d->B == 0 || d->H == 0 || d->Lq == 0) return GNLP_OK;
   const float inv_t = temperature > 0.0f ? 1.0f / temperature : 1.0f;
   FusedAttn fa;
@@ -236,11 +239,16 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
       fa.bias_f32 = 1;
     }
     fa.inv_temperature = inv_t;
+    fa.lse = lse;
+    fa.o_lo = ctx_lo;
     launch_fused_attn_bf16(fa, s);
     g_attn_kernel = GNLP_ATTN_KERNEL_FUSED_BF16;
     return check_launch("fused attention");
   }
   if (cu) return fail(GNLP_ERR_UNSUPPORTED, "packed batches need the fused bf16 attention kernel");
+  if (lse)
+    return fail(GNLP_ERR_UNSUPPORTED, "only the fused bf16 attention kernel (bf16, dk = dv = 64, "
+                "16-byte aligned rows) writes the row statistics");
   {   // ---- general MFMA kernel: fp32, other head dims, scores / weights wanted; no workspace ----
     GenAttn ga;
     memset(&ga, 0, sizeof(ga));
@@ -686,6 +694,32 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
                    workspace_bytes, S(stream));
 }
 
+int gnlp_multi_head_dot_attn_lse(void *ctx, void *ctx_lo, float *lse, const void *q, const void *k,
+                                 const void *v, const gnlp_attn_desc *d, int dtype,
+                                 const uint8_t *mask, const int64_t mask_stride[3],
+                                 const void *valid_length, int vl_dtype, const void *edge_scores,
+                                 const int64_t edge_stride[4], float temperature,
+                                 gnlp_stream_t stream) {
+  REQUIRE(lse != nullptr && ctx_lo != nullptr, "lse / ctx_lo is NULL");
+  REQUIRE(((uintptr_t)lse & 3) == 0, "lse must be 4-byte aligned");
+  REQUIRE(((uintptr_t)ctx_lo & 15) == 0, "ctx_lo must be 16-byte aligned");
+  REQUIRE(d != nullptr, "descriptor is NULL");
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(d->B >= 0 && d->H >= 0 && d->Lq >= 0 && d->Lm >= 0 && d->dk >= 0 && d->dv >= 0,
+          "negative shape");
+  REQUIRE(!mask || mask_stride, "mask given without strides");
+  REQUIRE(!edge_scores || edge_stride, "edge_scores given without strides");
+  REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
+  REQUIRE(d->B * d->H <= 0x7fffffffLL, "batch*heads too large");
+  REQUIRE(!(mask && d->causal), "d->causal selects the in-kernel predicate: mask must be NULL");
+  if (d->B * d->H * d->Lq * d->dv == 0 || d->Lm == 0 || d->dk == 0)
+    return fail(GNLP_ERR_UNSUPPORTED, "empty axis: use gnlp_multi_head_dot_attn");
+  REQUIRE(ctx && q && k && v, "NULL tensor");
+  return attn_impl(ctx, nullptr, nullptr, q, k, v, d, dtype, mask, mask_stride, valid_length,
+                   vl_dtype, edge_scores, edge_stride, temperature, nullptr, 0, S(stream), nullptr,
+                   nullptr, lse, ctx_lo);
+}
+
 size_t gnlp_attn_backward_workspace_bytes(const gnlp_attn_desc *d) {
   if (!d || d->B < 0 || d->H < 0 || d->Lq < 0) return 0;
   const size_t n = (size_t)d->B * (size_t)d->H * (size_t)d->Lq * 2 * sizeof(float);
@@ -744,6 +778,14 @@ int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edg
   a.causal = (!mask && d->causal) ? 1 : 0;
   a.bias = edge_scores;
   a.inv_temperature = temperature > 0.0f ? 1.0f / temperature : 1.0f;
+  REQUIRE((gd->fwd_ctx == nullptr) == (gd->fwd_lse == nullptr) &&
+          (gd->fwd_ctx_lo == nullptr) == (gd->fwd_lse == nullptr),
+          "fwd_ctx, fwd_ctx_lo and fwd_lse come together (gnlp_multi_head_dot_attn_lse) or not at all");
+  REQUIRE(((uintptr_t)gd->fwd_lse & 3) == 0, "fwd_lse must be 4-byte aligned");
+  a.fwd_lse = gd->fwd_lse;
+  a.fwd_o = gd->fwd_ctx;
+  a.fwd_o_lo = gd->fwd_ctx_lo;
+  for (int i = 0; i < 3; ++i) a.os[i] = d->o_stride[i];
   if (!attn_bwd_supported(a))
     return fail(GNLP_ERR_UNSUPPORTED, "attention backward: head dims %lld / %lld > 128 (or the "
                 "grid limit) are not supported", (long long)d->dk, (long long)d->dv);

@@ -92,6 +92,13 @@ attn_fwd_bf16_d64(FusedAttn a) {
 #pragma unroll
       for (int g = 0; g < 8; ++g)
         *reinterpret_cast<bf16x4 *>(obase + my_q * a.os[2] + g * 8 + hh * 4) = z;
+      if (a.lse) {   // training (never packed): statistics and rounding residual of a zero row
+        if (hh == 0) a.lse[(b * a.H + h) * a.Lq + my_q] = 0.0f;
+        bf16 *const lbase = (bf16 *)a.o_lo + b * a.os[0] + h * a.os[1];
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          *reinterpret_cast<bf16x4 *>(lbase + my_q * a.os[2] + g * 8 + hh * 4) = z;
+      }
     }
     return;
   }
@@ -347,6 +354,8 @@ attn_fwd_bf16_d64(FusedAttn a) {
   // global stores are full 128-byte rows, 16 bytes per lane.
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (a.lse && hh == 0 && my_q < a.Lq)   // training: what the backward kernels rebuild P from
+    a.lse[(b * a.H + h) * a.Lq + my_q] = l_tot > 0.0f ? m_run + __builtin_amdgcn_logf(l_tot) : 0.0f;
   char *ow = smem + wave * 4096;   // K/V tiles are dead: the loop ended with a barrier
 #pragma unroll
   for (int d = 0; d < 2; ++d)
@@ -369,6 +378,35 @@ attn_fwd_bf16_d64(FusedAttn a) {
     const bf16x8 o8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     const int64_t qq = q0 + wave * 32 + row;
     if (qq < q_store) *reinterpret_cast<bf16x8 *>(obase + qq * a.os[2] + oc * 8) = o8;
+  }
+  if (a.lse) {   // uniform.  Training: the residual of ctx's bf16 rounding, same route
+    bf16 *const lbase = (bf16 *)a.o_lo + b * a.os[0] + h * a.os[1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = oacc[d][g * 4 + e] * inv_l;
+          o[e] = (bf16)(x - (float)(bf16)x);
+        }
+        const int slot = d * 8 + g * 2 + hh;
+        *reinterpret_cast<bf16x4 *>(ow + r * 128 + ((slot ^ (r & 15)) << 3)) = o;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + orow0;
+      const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(ow + row * 128 + (((2 * oc) ^ (row & 15)) << 3));
+      const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(ow + row * 128 + (((2 * oc + 1) ^ (row & 15)) << 3));
+      const bf16x8 o8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      const int64_t qq = q0 + wave * 32 + row;
+      if (qq < a.Lq) *reinterpret_cast<bf16x8 *>(lbase + qq * a.os[2] + oc * 8) = o8;
+    }
   }
 }
 

@@ -313,39 +313,58 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
     }
   };
 
-  // ---- pass 1: m, l and sum_j exp(x_j - m) dP_j, rescaled together (base-2 units) ----
-  float m_run = BB_NEG, l_run = 0.0f, d_run = 0.0f;
-  sweep([&](const char *Kr, const char *Vr, int kb, int jb, auto full_c) {
-    constexpr bool FULL = decltype(full_c)::value;
-    f32x16 sacc, dpacc;
-    dot_blocks(Kr, Vr, kb, sacc, dpacc);
-    unsigned on = 0xffffu;
-    if (!FULL) on = gen ? bias_mask_block(jb, sacc) : bits_below(klim - jb - 4 * hh);
-    float mloc = BB_NEG;
+  // ---- row statistics: lse (base-2 units) and D = sum_j P_j dP_j ----
+  float lse2 = 0.0f, dsum = 0.0f;
+  if (a.fwd_lse) {   // uniform.  Saved by the forward kernel: its lse, and D = <dO, O> with O
+                     // to 16 bits (the bf16 output + the residual of its rounding)
+    const int64_t qrow = my_q < a.Lq ? my_q : a.Lq - 1;
+    const int64_t ooff = b * a.os[0] + h * a.os[1] + qrow * a.os[2];
+    const bf16 *og = (const bf16 *)a.fwd_o + ooff, *ol = (const bf16 *)a.fwd_o_lo + ooff;
+    float acc = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      if (FULL || (on & (1u << e))) mloc = fmaxf(mloc, sacc[e]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float mz = mloc > -1.0e29f ? mloc * c_scale : BB_NEG;
-    if (mz > m_run) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - mz);   // m_run = BB_NEG: both sums are 0
-      l_run *= alpha;
-      d_run *= alpha;
-      m_run = mz;
-    }
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 o8 = *reinterpret_cast<const bf16x8 *>(og + 16 * s + 8 * hh);
+      const bf16x8 l8 = *reinterpret_cast<const bf16x8 *>(ol + 16 * s + 8 * hh);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float w = __builtin_amdgcn_exp2f(fmaf(sacc[e], c_scale, -m_run));
-      if (!FULL) w = (on & (1u << e)) ? w : 0.0f;
-      l_run += w;
-      d_run = fmaf(w, dpacc[e], d_run);
+      for (int i = 0; i < 8; ++i) acc = fmaf((float)gf[s][i], (float)o8[i] + (float)l8[i], acc);
     }
-  });
-  l_run += __shfl_xor(l_run, 32, 64);
-  d_run += __shfl_xor(d_run, 32, 64);
-  const bool any_on = l_run > 0.0f;
-  const float lse2 = any_on ? m_run + __builtin_amdgcn_logf(l_run) : 0.0f;   // fully masked: P = 0
-  const float dsum = any_on ? d_run / l_run : 0.0f;
+    dsum = acc + __shfl_xor(acc, 32, 64);
+    lse2 = a.fwd_lse[(b * a.H + h) * a.Lq + qrow];
+  } else {
+    // pass 1: m, l and sum_j exp(x_j - m) dP_j, rescaled together
+    float m_run = BB_NEG, l_run = 0.0f, d_run = 0.0f;
+    sweep([&](const char *Kr, const char *Vr, int kb, int jb, auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      f32x16 sacc, dpacc;
+      dot_blocks(Kr, Vr, kb, sacc, dpacc);
+      unsigned on = 0xffffu;
+      if (!FULL) on = gen ? bias_mask_block(jb, sacc) : bits_below(klim - jb - 4 * hh);
+      float mloc = BB_NEG;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (FULL || (on & (1u << e))) mloc = fmaxf(mloc, sacc[e]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mz = mloc > -1.0e29f ? mloc * c_scale : BB_NEG;
+      if (mz > m_run) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mz);   // m_run = BB_NEG: both sums are 0
+        l_run *= alpha;
+        d_run *= alpha;
+        m_run = mz;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float w = __builtin_amdgcn_exp2f(fmaf(sacc[e], c_scale, -m_run));
+        if (!FULL) w = (on & (1u << e)) ? w : 0.0f;
+        l_run += w;
+        d_run = fmaf(w, dpacc[e], d_run);
+      }
+    });
+    l_run += __shfl_xor(l_run, 32, 64);
+    d_run += __shfl_xor(d_run, 32, 64);
+    const bool any_on = l_run > 0.0f;
+    lse2 = any_on ? m_run + __builtin_amdgcn_logf(l_run) : 0.0f;   // fully masked: P = 0
+    dsum = any_on ? d_run / l_run : 0.0f;
+  }
   if (wave_live && hh == 0 && my_q < a.Lq) {
     float *st = a.stats + ((b * a.H + h) * a.Lq + my_q) * 2;
     st[0] = lse2;
@@ -585,7 +604,13 @@ bool attn_bwd_bf16_supported(const GenAttnBwd &a) {
   return nb * a.H * a.B <= 0x7fffffffLL;
 }
 
-void launch_attn_bwd_bf16(const GenAttnBwd &a, hipStream_t s) {
+void launch_attn_bwd_bf16(const GenAttnBwd &a_in, hipStream_t s) {
+  GenAttnBwd a = a_in;
+  if (a.fwd_lse && (!a.fwd_o || !a.fwd_o_lo || ((uintptr_t)a.fwd_o | (uintptr_t)a.fwd_o_lo) % 16 != 0 ||
+                    a.os[0] % 8 != 0 || a.os[1] % 8 != 0 || a.os[2] % 8 != 0)) {
+    a.fwd_lse = nullptr;   // rows of the saved output are not 16-byte aligned: recompute
+    a.fwd_o = a.fwd_o_lo = nullptr;
+  }
   const int64_t nqb = (a.Lq + 127) / 128, nkb = (a.Lm + 127) / 128;
   attn_bwd_q_bf16_kernel<<<dim3((unsigned)(nqb * a.H * a.B)), 256, kLdsQ, s>>>(a);
   attn_bwd_kv_bf16_kernel<<<dim3((unsigned)(nkb * a.H * a.B)), 256, kLdsKV, s>>>(a);

@@ -170,6 +170,11 @@ struct FusedAttn {
   int64_t bs[4];                        // (b, h, i, j)
   int bias_f32;                         // bias holds float32 (no mask, not causal): the stack's copy
   float inv_temperature;
+  float *lse;                           // or null; (B, H, Lq) fp32: log2 of the softmax denominator of
+                                        // the scores in base-2 units (s * log2(e) / temperature), what
+                                        // the backward kernels rebuild P from; 0 for a fully masked row
+  void *o_lo;                           // with lse: bf16, laid out like o: bf16(ctx_fp32 - bf16(ctx_fp32)),
+                                        // so that the backward's D = <dO, O> sees O to 16 bits
 };
 void launch_widen_bf16(float *out, const void *in, int64_t n, hipStream_t s);
 bool fused_attn_supported(const FusedAttn &a, int64_t dk, int64_t dv);
@@ -229,6 +234,11 @@ struct GenAttnBwd {
   const void *bias;
   int64_t bs[4];
   float inv_temperature;
+  // saved by the forward (both or neither; only the bf16 kernels use them): its output and its
+  // FusedAttn::lse -- the statistics pass is skipped, D = <dO, O>
+  const float *fwd_lse;
+  const void *fwd_o, *fwd_o_lo;
+  int64_t os[3];
 };
 bool attn_bwd_supported(const GenAttnBwd &a);
 void launch_attn_bwd(const GenAttnBwd &a, int dtype, hipStream_t s);

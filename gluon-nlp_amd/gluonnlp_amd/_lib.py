@@ -33,7 +33,8 @@ class AttnDesc(Structure):
 
 class AttnGradDesc(Structure):
     _fields_ = [('g_stride', c_int64 * 3), ('dq_stride', c_int64 * 3),
-                ('dk_stride', c_int64 * 3), ('dv_stride', c_int64 * 3)]
+                ('dk_stride', c_int64 * 3), ('dv_stride', c_int64 * 3),
+                ('fwd_ctx', c_void_p), ('fwd_ctx_lo', c_void_p), ('fwd_lse', c_void_p)]
 
 
 class FfnParams(Structure):
@@ -103,6 +104,10 @@ PROTOTYPES = {
                                          c_void_p, POINTER(AttnDesc), c_int, c_void_p,
                                          POINTER(c_int64), c_void_p, c_int, c_void_p,
                                          POINTER(c_int64), c_float, c_void_p, c_size_t, c_void_p]),
+    'gnlp_multi_head_dot_attn_lse': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, POINTER(AttnDesc), c_int, c_void_p, POINTER(c_int64),
+                                             c_void_p, c_int, c_void_p, POINTER(c_int64), c_float,
+                                             c_void_p]),
     'gnlp_attn_backward_workspace_bytes': (c_size_t, [POINTER(AttnDesc)]),
     'gnlp_multi_head_dot_attn_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                                   POINTER(c_int64), c_void_p, c_void_p, c_void_p,

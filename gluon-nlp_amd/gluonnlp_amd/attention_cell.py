@@ -237,7 +237,10 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
         e = e.to(q.dtype)
     temperature = 0.0 if scale is None else float(scale)
 
-    def call(q, k, v, e):
+    def call(q, k, v, e, want_lse=False):
+        """-> ctx, scores, weights[, saved]: with want_lse (a backward pass will follow) the fused
+        bf16 kernel also leaves (lse, ctx_lo) = its row statistics and the residual of ctx's
+        rounding (None when another kernel serves the call)."""
         d = desc(q, k, v)
         ctx = torch.empty((Lq, B, H * dv) if layout == 'TNK' else (B, Lq, H * dv), dtype=q.dtype,
                           device=dev)
@@ -250,6 +253,18 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
         scores = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_scores else None
         weights = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_weights else None
         lib = _lib.load()
+        if want_lse:
+            if (not _need_scores and not _need_weights and q.dtype == torch.bfloat16
+                    and dk == 64 and dv == 64 and B * H * Lq * Lm > 0):
+                lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev)
+                ctx_lo = torch.empty_like(ctx)
+                rc = lib.gnlp_multi_head_dot_attn_lse(
+                    T.ptr(ctx), T.ptr(ctx_lo), T.ptr(lse), T.ptr(q), T.ptr(k), T.ptr(v),
+                    ctypes.byref(d), T.code(q), mptr, ms, vlp, vlc, eptr, es, temperature,
+                    T.stream(dev))
+                if rc == 0:
+                    return ctx, None, None, (lse, ctx_lo)
+            return call(q, k, v, e) + (None,)
         nws = lib.gnlp_attn_workspace_bytes(ctypes.byref(d), T.code(q), int(_need_scores),
                                             int(_need_weights))
         fused_ok = (not _need_scores and not _need_weights and q.dtype == torch.bfloat16

@@ -41,9 +41,13 @@ class AttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, e, call, state):
-        out, scores, weights = call(q, k, v, e)
-        ctx.save_for_backward(q, k, v, e if e is not None else torch.empty(0, device=q.device))
+        out, scores, weights, saved = call(q, k, v, e, want_lse=True)
+        none = torch.empty(0, device=q.device)
+        # with the fused kernel's row statistics the backward skips its own statistics pass
+        ctx.save_for_backward(q, k, v, e if e is not None else none,
+                              *((out, saved[1], saved[0]) if saved is not None else (none,) * 3))
         ctx.has_e = e is not None
+        ctx.has_lse = saved is not None
         ctx.state = state
         marks = [t for t in (scores, weights) if t is not None]
         if marks:
@@ -52,7 +56,7 @@ class AttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_scores, _g_weights):
-        q, k, v, e = ctx.saved_tensors
+        q, k, v, e, fwd_out, fwd_out_lo, fwd_lse = ctx.saved_tensors
         e = e if ctx.has_e else None
         st = ctx.state
         dev = q.device
@@ -69,6 +73,9 @@ class AttnFn(torch.autograd.Function):
         gd.dq_stride[:] = st['bht'](dq, layout)
         gd.dk_stride[:] = st['bht'](dk, layout)
         gd.dv_stride[:] = st['bht'](dv, layout)
+        if ctx.has_lse:
+            gd.fwd_ctx, gd.fwd_ctx_lo, gd.fwd_lse = \
+                fwd_out.data_ptr(), fwd_out_lo.data_ptr(), fwd_lse.data_ptr()
         if B * H * Lq * Lm * d.dk * d.dv == 0:       # an empty axis: every gradient is zero
             return (dq.zero_(), dk.zero_(), dv.zero_(),
                     torch.zeros_like(e) if e is not None and ctx.needs_input_grad[3] else None,

@@ -204,6 +204,21 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
                              const int64_t edge_stride[4], float temperature, void *workspace,
                              size_t workspace_bytes, gnlp_stream_t stream);
 
+/* gnlp_multi_head_dot_attn for a caller that will ask for gradients (mx.autograd.record() around
+ * multi_head_dot_attn, tests/test_attention_cell.py:82-151): ctx as above (no scores / weights),
+ * plus lse (B, H, Lq) float32 = log2 of the row's softmax denominator with the scores in base-2
+ * units (s * log2(e) / temperature; 0 for a fully masked row) and ctx_lo (bf16, shaped and strided
+ * like ctx) = the residual of ctx's rounding to bf16, to be handed to
+ * gnlp_multi_head_dot_attn_backward through gnlp_attn_grad_desc.  Only the fused bf16 kernel
+ * (bf16, dk = dv = 64, 16-byte aligned rows) produces it: GNLP_ERR_UNSUPPORTED otherwise, nothing
+ * launched -- call gnlp_multi_head_dot_attn and leave the grad desc's pointers NULL. */
+int gnlp_multi_head_dot_attn_lse(void *ctx, void *ctx_lo, float *lse, const void *q, const void *k,
+                                 const void *v, const gnlp_attn_desc *d, int dtype,
+                                 const uint8_t *mask, const int64_t mask_stride[3],
+                                 const void *valid_length, int vl_dtype, const void *edge_scores,
+                                 const int64_t edge_stride[4], float temperature,
+                                 gnlp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward pass.  The reference takes these gradients with mx.autograd through
  * the forward ops; its tests drive them through multi_head_dot_attn for query / key / value /
@@ -231,6 +246,15 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
  * GNLP_ATTN_BWD_BF16=0 (developer knob) keeps them on the f32-MFMA kernels. */
 typedef struct {
   int64_t g_stride[3], dq_stride[3], dk_stride[3], dv_stride[3];
+  /* Optional, all three or none: what gnlp_multi_head_dot_attn_lse left for this call -- its ctx
+   * and ctx_lo (addressed with d->o_stride) and its lse.  The bf16 kernels then skip their
+   * statistics pass (2 of 9 matrix products) and take D = <grad_ctx, ctx + ctx_lo> per row, as the
+   * usual flash-attention backward does (but with the output to 16 bits: with the bf16 ctx alone
+   * the rounding of ctx reaches the gradients of rows that see only a few keys); the general
+   * kernels ignore them and recompute. */
+  const void *fwd_ctx;
+  const void *fwd_ctx_lo;
+  const float *fwd_lse;
 } gnlp_attn_grad_desc;
 
 size_t gnlp_attn_backward_workspace_bytes(const gnlp_attn_desc *d);

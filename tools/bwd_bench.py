@@ -32,10 +32,13 @@ for dtype in (torch.bfloat16, torch.float32):
     fwd = timed(lambda: ac.multi_head_dot_attn(q.detach(), k.detach(), v.detach(), mask, scaled=True,
                                                query_head_units=d, layout='NTK', _need_scores=False,
                                                _need_weights=False))
+    fwd_t = timed(lambda: ac.multi_head_dot_attn(q, k, v, mask, scaled=True, query_head_units=d,
+                                                 layout='NTK', _need_scores=False,
+                                                 _need_weights=False))
     bwd = timed(lambda: torch.autograd.grad(out, (q, k, v), g, retain_graph=True))
     fl = 4.0 * B * H * L * L * d
-    print('attention %s B=%d: fwd %.1f us (%.0f TF), bwd %.1f us (%.0f TF counting 2.5x fwd flops + '
-          'recompute 2x)' % (dtype, B, fwd, fl / fwd / 1e6, bwd, 4.5 * fl / bwd / 1e6))
+    print('attention %s B=%d: fwd %.1f us (%.0f TF; %.1f us when a backward will follow), bwd %.1f us'
+          % (dtype, B, fwd, fl / fwd / 1e6, fwd_t, bwd))
     rows, C = 32768, 1024
     ln = LayerNorm(epsilon=1e-12, in_channels=C, dtype='bfloat16' if dtype == torch.bfloat16 else 'float32').cuda()
     ln.gamma.requires_grad_(True); ln.beta.requires_grad_(True)
