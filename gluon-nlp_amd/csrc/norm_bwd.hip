@@ -88,13 +88,20 @@ norm_bwd_kernel(T *__restrict__ dx, float *__restrict__ dgamma, float *__restric
         if (c < C) dr[c] = from_f32<T>(rstd * (go[i] - m1 - v[i] * m2));
       }
     }
+    // the four waves add their partial sums in turn, with plain LDS accesses: as LDS float
+    // atomics this step cost ~8 us per workgroup (tools/bwd_bench.py: 117 -> 60 us at 32768 x 1024)
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) {
-        atomicAdd(&acc_lds[c], pg[i]);
-        atomicAdd(&acc_lds[C + c], pb[i]);
+        for (int i = 0; i < MAXE; ++i) {
+          const int c = lane + 64 * i;
+          if (c < C) {
+            acc_lds[c] += pg[i];
+            acc_lds[C + c] += pb[i];
+          }
+        }
       }
+      __syncthreads();
     }
   } else {
     // any C that fits the LDS accumulators: three passes over the (L2-resident) row
@@ -169,26 +176,41 @@ norm_bwd_vec_kernel(T *__restrict__ dx, float *__restrict__ dgamma, float *__res
       gam[i][q] = vi < nvec ? to_f32(gamma[vi * N + q]) : 0.0f;
     }
   }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+  // the loads of the wave's NEXT row are issued before the current one is reduced: a row is four
+  // dependent wave reductions long, and with the loads inside that chain the kernel ran at a
+  // third of the memory rate
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  V na[MAXV], nb[MAXV], nr[MAXV];
+  auto fetch = [&](int64_t row) {
     const T *xr = x + row * C, *gr = g + row * C;
     const T *rr = residual ? residual + row * C : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        na[i] = __builtin_nontemporal_load(reinterpret_cast<const V *>(xr + vi * N));
+        nb[i] = __builtin_nontemporal_load(reinterpret_cast<const V *>(gr + vi * N));
+        if (rr) nr[i] = __builtin_nontemporal_load(reinterpret_cast<const V *>(rr + vi * N));
+      }
+    }
+  };
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
     float v[MAXV][N], go[MAXV][N];
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        const V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(xr + vi * N));
-        const V b = __builtin_nontemporal_load(reinterpret_cast<const V *>(gr + vi * N));
 #pragma unroll
         for (int q = 0; q < N; ++q) {
-          v[i][q] = to_f32(a[q]);
-          go[i][q] = to_f32(b[q]);
+          v[i][q] = to_f32(na[i][q]);
+          go[i][q] = to_f32(nb[i][q]);
         }
-        if (rr) {
-          const V r = __builtin_nontemporal_load(reinterpret_cast<const V *>(rr + vi * N));
+        if (residual) {
 #pragma unroll
-          for (int q = 0; q < N; ++q) v[i][q] += to_f32(r[q]);
+          for (int q = 0; q < N; ++q) v[i][q] += to_f32(nr[i][q]);
         }
 #pragma unroll
         for (int q = 0; q < N; ++q) s += v[i][q];
@@ -197,6 +219,7 @@ norm_bwd_vec_kernel(T *__restrict__ dx, float *__restrict__ dgamma, float *__res
         for (int q = 0; q < N; ++q) v[i][q] = go[i][q] = 0.0f;
       }
     }
+    if (row + stride < rows) fetch(row + stride);
     float mean = 0.0f, rstd = 1.0f;
     if (kind == GNLP_NORM_LAYER) {
       mean = wave_sum(s) * invC;
@@ -245,18 +268,25 @@ norm_bwd_vec_kernel(T *__restrict__ dx, float *__restrict__ dgamma, float *__res
       }
     }
   }
+  // the four waves add their partial sums in turn, with plain 16-byte LDS accesses (see above)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int vi = lane + 64 * i;
-    if (vi < nvec) {
+      for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
 #pragma unroll
-      for (int q = 0; q < N; ++q) {
-        atomicAdd(&acc_lds[vi * N + q], pg[i][q]);
-        atomicAdd(&acc_lds[C + vi * N + q], pb[i][q]);
+          for (int q = 0; q < N; q += 4) {
+            f32x4 *ag = reinterpret_cast<f32x4 *>(&acc_lds[vi * N + q]);
+            f32x4 *ab = reinterpret_cast<f32x4 *>(&acc_lds[C + vi * N + q]);
+            *ag += (f32x4){pg[i][q], pg[i][q + 1], pg[i][q + 2], pg[i][q + 3]};
+            *ab += (f32x4){pb[i][q], pb[i][q + 1], pb[i][q + 2], pb[i][q + 3]};
+          }
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     atomicAdd(&dgamma[c], acc_lds[c]);
     atomicAdd(&dbeta[c], acc_lds[C + c]);
