@@ -17,7 +17,10 @@
 //     of a 32-block, which is the order the transposing read delivers;
 //   * 32-blocks whose elements are all switched on (no bias, no dense mask, inside valid_length and
 //     below the causal diagonal) take a path without per-element predicates; statistics are kept
-//     in base-2 units (exp2 of one fused multiply-add); 1 / temperature is applied once to dQ / dK.
+//     in base-2 units (exp2 of one fused multiply-add); 1 / temperature is applied once to dQ / dK;
+//   * when the forward ran the fused kernel for a caller that wants gradients it left lse and the
+//     residual of ctx's bf16 rounding (FusedAttn::lse, o_lo): kernel A then skips its statistics
+//     pass and takes D = <dO, ctx + ctx_lo>.
 #include <type_traits>
 
 #include "common.h"
