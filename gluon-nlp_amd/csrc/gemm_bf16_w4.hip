@@ -514,13 +514,22 @@ bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, 
 // narrower tile does not pay: at N = 768, M = 32768, 512 tiles of 192 (two full rounds of 3/4 the
 // work) ran 1.3 % slower end to end than 384 tiles of 256 (a half-empty second round) -- these
 // GEMMs are power-limited, idle CUs lift the clock of the busy ones, and the narrower tile moves
-// 17 % more bytes per flop.  GNLP_GEMM_NT=256 / 192 is the developer knob.
-static int w4_tile_width(int64_t M, int64_t N, int cus) {
+// 17 % more bytes per flop.  It does pay when the 256-wide tiles leave a last round less than
+// half full and the 192-wide ones fill theirs: T5-base QKV, M = 16384, N = 2304: 576 tiles = 2.25
+// rounds against 768 = 3 rounds of 3/4 the work, 65 -> 55 us, +1.2 % end to end with FFN-1
+// (N = 3072: 3 rounds against 4) left at 256; not with a row count read from the device (packed
+// ragged batches: M is only an upper bound).  GNLP_GEMM_NT=256 / 192 is the developer knob.
+static int w4_tile_width(int64_t M, int64_t N, int cus, bool m_is_bound) {
   if (N % 192 != 0) return 256;
   if (N % 256 != 0) return 192;
   if (knobs().gemm_nt) return knobs().gemm_nt;
   const int64_t tm = M / 256;
-  return tm * (N / 256) < cus && tm * (N / 192) <= cus ? 192 : 256;
+  const int64_t t256 = tm * (N / 256), t192 = tm * (N / 192);
+  if (t256 < cus && t192 <= cus) return 192;
+  if (!m_is_bound && t256 > cus && t192 % cus == 0 && t256 % cus != 0 && 2 * (t256 % cus) < cus &&
+      (t192 / cus) * 3 < ((t256 + cus - 1) / cus) * 4)
+    return 192;
+  return 256;
 }
 
 static int w4_cu_count() {   // of the current device
@@ -574,7 +583,7 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   a.K = (int)K; a.nk = (int)(K >> 6); a.combine = combine;
   a.tiles_m = (int)(M / 256);
   a.rows_dev = dense_rows_dev();
-  const int width = w4_tile_width(M, N, w4_cu_count() & ~7);
+  const int width = w4_tile_width(M, N, w4_cu_count() & ~7, a.rows_dev != nullptr);
   a.tiles_n = (int)(N / width);
   a.group_m = knobs().group_m;
   switch (act) {
