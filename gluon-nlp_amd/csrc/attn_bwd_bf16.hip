@@ -589,8 +589,9 @@ static_assert(kLdsKV <= 64 * 1024, "static LDS limit");
 
 }  // namespace
 
-// bf16, dk = dv = 64, 16-byte aligned rows of the inputs and the outputs (16-byte accesses), positive temperature (the running maximum is taken before scaling), sequence
-// lengths that fit the 32-bit position arithmetic
+// bf16, dk = dv = 64, 16-byte aligned rows of the inputs and the outputs (16-byte accesses),
+// positive temperature (the running maximum is taken before scaling), sequence lengths that fit
+// the 32-bit position arithmetic
 bool attn_bwd_bf16_supported(const GenAttnBwd &a) {
   if (a.dk != 64 || a.dv != 64) return false;
   if (a.B < 1 || a.H < 1 || a.Lq < 1 || a.Lm < 1) return false;
