@@ -226,7 +226,9 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
   if (d->B == 0 || d->H == 0 || d->Lq == 0) return GNLP_OK;
   const float inv_t = temperature > 0.0f ? 1.0f / temperature : 1.0f;
   FusedAttn fa;
-  if (!scores_out && !weights_out && can_fuse(d, dtype, q, k, v, ctx, edge, es, &fa)) {
+  // (the fused kernel reads mask rows as 16-byte pieces along the key axis: unit key stride)
+  if (!scores_out && !weights_out && (!mask || ms[2] == 1) &&
+      can_fuse(d, dtype, q, k, v, ctx, edge, es, &fa)) {
     fa.cu = cu;
     fa.mask = mask;
     if (mask) { fa.ms[0] = ms[0]; fa.ms[1] = ms[1]; fa.ms[2] = ms[2]; }

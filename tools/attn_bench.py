@@ -24,6 +24,8 @@ def run(B, L, H, d=64, bias=False, ragged=False, iters=20):
 
 if __name__ == '__main__':
   for name, args in [('bert_large B64 L512', (64, 512, 16)), ('bert_base B256 L128', (256, 128, 12)),
-                     ('t5 B16 L1024 bias', (16, 1024, 12, 64, True)), ('bert_large ragged', (64, 512, 16, 64, False, True))]:
+                     ('t5 B16 L1024 bias', (16, 1024, 12, 64, True)), ('t5 B16 L1024 no bias', (16, 1024, 12, 64, False)),
+                     ('t5 bias ragged', (16, 1024, 12, 64, True, True)), ('t5 no bias ragged', (16, 1024, 12, 64, False, True)),
+                     ('bert_large ragged', (64, 512, 16, 64, False, True))]:
     ms, tf = run(*args)
     print('%-22s %.1f us  %.0f TF (dense-equivalent)' % (name, ms * 1e3, tf), flush=True)
