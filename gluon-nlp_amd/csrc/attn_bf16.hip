@@ -374,10 +374,15 @@ attn_fwd_bf16_d64(FusedAttn a) {
       for (int e = 0; e < 16; e += 2)            // fmax(fmax(m, a), b) = one v_max3_f32
         mloc = fmaxf(fmaxf(mloc, sacc[kb][e]), sacc[kb][e + 1]);
     {   // lane ^ 32 exchange in the vector ALU (v_permlane32_swap) instead of an LDS round trip
-      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-      const unsigned mu = __builtin_bit_cast(unsigned, mloc);
-      const u32x2 sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-      mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+      // As inline assembly: through __builtin_amdgcn_permlane32_swap hipcc 7.2 drops the maximum
+      // of the two results (no v_max after the swap in the ISA, whether the operands are the same
+      // value or not) and the running maximum then only sees the keys of the lower lane half --
+      // harmless while both halves hold similar scores, an overflow of exp2 (inf / inf = NaN) when
+      // the largest score of a row sits in the upper half, e.g. when every key of the lower half
+      // is masked.  tests/test_gpu_encoder.py::test_fused_attention_max_over_both_lane_halves
+      unsigned ma = __builtin_bit_cast(unsigned, mloc), mb = ma;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+      mloc = fmaxf(__builtin_bit_cast(float, ma), __builtin_bit_cast(float, mb));
     }
     const float mz = mloc > -1.0e29f ? mloc * c_scale : NEG_BIG;   // scaled units
     if (__any(mz > m_run + RESCALE_THR)) {                          // wave-uniform

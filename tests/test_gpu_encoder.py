@@ -613,3 +613,79 @@ def test_packed_ragged_stack_edge_batches(nlp, B, L, case):
     if bool((~live).any()):
         assert float(got[~live].float().abs().max()) == 0.0
     assert torch.isfinite(got.float()).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('attn_type', ['full', 'causal'])
+@pytest.mark.parametrize('L', [200, 512])
+def test_fused_attention_dense_mask_blocks(nlp, attn_type, L):
+    """The dense-mask variant of the fused kernel on masks made of whole blocks: the bytes of a
+    gen_self_attn_mask product handed over untagged.  Blocks that are switched on entirely take
+    the path without per-element selects, blocks switched off entirely are skipped, the ragged
+    ones go element by element -- bit for bit the output of the in-kernel predicate; the same with
+    a bias on top."""
+    ac = nlp.attention_cell
+    B, H, d = 4, 2, 64
+    gen = torch.Generator(device='cuda').manual_seed(L)
+    q, k, v = [torch.randn((B, L, H, d), device='cuda', generator=gen).to(torch.bfloat16)
+               for _ in range(3)]
+    e = torch.randn((H, L, L), device='cuda', generator=gen).to(torch.bfloat16)
+    vl = torch.tensor([L, L // 2 + 3, 1, 130], device='cuda')
+    tagged = ac.gen_self_attn_mask(torch.zeros((B, L, 1), device='cuda'), vl, attn_type=attn_type)
+    dense = tagged.clone()
+    assert ac.mask_predicate(dense) is None
+    kw = dict(scaled=True, query_head_units=d, layout='NTK', _need_scores=False, _need_weights=False)
+    for bias in (None, e):
+        a, _ = ac.multi_head_dot_attn(q, k, v, tagged, bias, **kw)
+        assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_FUSED_BF16
+        b, _ = ac.multi_head_dot_attn(q, k, v, dense, bias, **kw)
+        assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_FUSED_BF16
+        assert torch.equal(a, b)
+    # a mask whose key stride is not 1 (a transposed view) goes to the general kernel
+    tview = dense.transpose(1, 2)
+    c, _ = ac.multi_head_dot_attn(q, k, v, tview, None, **kw)
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_GENERAL_MFMA
+    ref_c, _ = ac.multi_head_dot_attn(q, k, v, tview.contiguous(), None, **kw)
+    assert rel_err(to_np(c), to_np(ref_c)) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['mask_upper', 'mask_lower', 'spike_upper', 'spike_lower'])
+def test_fused_attention_max_over_both_lane_halves(nlp, case):
+    """Regression: in the fused kernel two lanes share a query row (keys with key % 8 < 4 and
+    >= 4); the row maximum must cover both.  It once covered the lower half only (the compiler
+    dropped the maximum behind the lane exchange): a row whose lower-half keys were all masked, or
+    whose largest un-scaled score sat on an upper-half key by more than 2^127, came out NaN."""
+    ac = nlp.attention_cell
+    B, H, L, d = 2, 2, 128, 64
+    rng = np.random.default_rng(7)
+    q, k, v = [rng.standard_normal((B, H, L, d)) for _ in range(3)]
+    mask_np = np.ones((B, L, L), dtype=bool)
+    scaled = True
+    if case.startswith('mask'):
+        mask_np[:] = False
+        lo = 60 if case == 'mask_upper' else 56        # keys 60..63 (upper half) / 56..59 (lower)
+        mask_np[:, :, lo:lo + 4] = True
+        mask_np[1, :, 68:72 if case == 'mask_upper' else 64:68] = True
+    else:
+        scaled = False                                 # T5: raw scores, no temperature
+        j = 13 if case == 'spike_upper' else 9         # 13 % 8 = 5 (upper half), 9 % 8 = 1 (lower)
+        k[:, :, j] = q[:, :, 5] * 8.0                  # score ~ 8 |q|^2 ~ 500 against |s| < 40
+    qq, kk, vv = [to_dev(np.transpose(x, (0, 2, 1, 3)), torch.bfloat16) for x in (q, k, v)]
+    mask = torch.tensor(mask_np, device='cuda')
+    ctx, _ = ac.multi_head_dot_attn(qq, kk, vv, mask, None, scaled=scaled, query_head_units=d,
+                                    layout='NTK', _need_scores=False, _need_weights=False)
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_FUSED_BF16
+    got = to_np(ctx)
+    assert np.isfinite(got).all()
+    ectx, _ = ref.multi_head_dot_attn(prep(q, torch.bfloat16), prep(k, torch.bfloat16),
+                                      prep(v, torch.bfloat16), mask_np, None, scaled=scaled,
+                                      query_head_units=d)
+    assert rel_err(got, ectx) < 2e-2
+    # the same through the in-kernel predicate (no dense mask): spikes only
+    if case.startswith('spike'):
+        vl = torch.tensor([L, L], device='cuda')
+        tagged = ac.gen_self_attn_mask(torch.zeros((B, L, 1), device='cuda'), vl)
+        ctx2, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged, None, scaled=scaled, query_head_units=d,
+                                         layout='NTK', _need_scores=False, _need_weights=False)
+        assert np.isfinite(to_np(ctx2)).all() and rel_err(to_np(ctx2), ectx) < 2e-2
