@@ -1,10 +1,11 @@
-"""Developer tool: error of the bf16 attention backward kernels (bf16-MFMA and fp32-MFMA paths)
+"""Developer script (kept under tests/: it uses the oracle, which only tests may import; not
+collected by pytest): error of the bf16 attention backward kernels (bf16-MFMA and fp32-MFMA paths)
 against the float64 oracle on one causal / ragged case."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gluon-nlp_amd'))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import gluonnlp_amd
 from gluonnlp_amd import _lib, attention_cell as ac

@@ -1,10 +1,11 @@
-"""Developer tool: error of the bf16 attention backward against the float64 oracle on un-scaled
+"""Developer script (kept under tests/: it uses the oracle, which only tests may import; not
+collected by pytest): error of the bf16 attention backward against the float64 oracle on un-scaled
 (peaked) scores: recomputed statistics, the forward's statistics, and the fp32-MFMA kernels."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gluon-nlp_amd'))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from gluonnlp_amd import _lib, attention_cell as ac
 from oracle import ref

@@ -401,7 +401,7 @@ def test_attention_backward_bf16_kernels_without_bias(nlp, attn_type, B, H, L, v
     general fp32-MFMA kernels (GNLP_ATTN_BWD_BF16=0).
 
     Tolerance: these kernels round P and dS to bf16 for the second matrix products (as the forward
-    kernel rounds P).  Measured with tools/bwd_err.py on the first case: rms error 0.0023 of
+    kernel rounds P).  Measured with tests/dev_bwd_err.py on the first case: rms error 0.0023 of
     rms(ref) against 0.0017 from rounding the exact gradient to bf16 alone (what the fp32-MFMA
     path shows), but heavy-tailed: early keys under the causal mask carry a few large dS terms
     that cancel in the sum, and one element of dk reaches 2.02e-2 on the element-wise metric.
