@@ -1,0 +1,75 @@
+"""Developer tool: randomized check of LayerNorm / RMSNorm (with the fused residual), forward and
+backward, and of masked_softmax, against torch float32 formulas + autograd over random row counts
+and widths (vector / scalar kernels, widths beyond the register image), bf16 and float32."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'gluon-nlp_amd'))
+import numpy as np
+import torch
+from gluonnlp_amd.layers import LayerNorm, RMSNorm
+from gluonnlp_amd import attention_cell as ac
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+bad = 0
+
+
+def metric(a, b):
+    rms = float(b.pow(2).mean().sqrt()) + 1e-9
+    return float(((a - b).abs() / (b.abs() + rms)).max())
+
+
+for it in range(ncase):
+    dtype = torch.bfloat16 if rng.random() < 0.6 else torch.float32
+    name = 'bfloat16' if dtype == torch.bfloat16 else 'float32'
+    rows = int(rng.choice([1, 3, 17, 255, 256, 1000, 4100]))
+    C = int(rng.choice([1, 7, 64, 96, 100, 768, 1024, 1536, 2048, 3000, 4096, 6000]))
+    kind = rng.choice(['ln', 'ln_res', 'rms'])
+    eps = float(rng.choice([1e-12, 1e-6, 1e-5]))
+    lim = 2e-2 if dtype == torch.bfloat16 else 2e-4
+    if kind == 'rms':
+        m = RMSNorm(in_channels=C, variance_epsilon=eps, dtype=name).cuda()
+    else:
+        m = LayerNorm(epsilon=eps, in_channels=C, dtype=name).cuda()
+    with torch.no_grad():
+        m.gamma.copy_(torch.tensor(1 + 0.2 * rng.standard_normal(C)))
+        m.beta.copy_(torch.tensor(0.2 * rng.standard_normal(C)))
+    m.gamma.requires_grad_(True)
+    m.beta.requires_grad_(True)
+    x = torch.tensor(rng.standard_normal((rows, C)) * 2 + 0.5, device='cuda').to(dtype).requires_grad_(True)
+    r = torch.tensor(rng.standard_normal((rows, C)), device='cuda').to(dtype).requires_grad_(True) \
+        if kind == 'ln_res' else None
+    go = torch.tensor(rng.standard_normal((rows, C)), device='cuda').to(dtype)
+    y = m(x, r) if kind == 'ln_res' else m(x)
+    gs = torch.autograd.grad(y, [x, m.gamma, m.beta] + ([r] if r is not None else []), go)
+    xf = x.detach().float().requires_grad_(True)
+    rf = r.detach().float().requires_grad_(True) if r is not None else None
+    gf, bf = m.gamma.detach().float().requires_grad_(True), m.beta.detach().float().requires_grad_(True)
+    s = xf + rf if rf is not None else xf
+    if kind == 'rms':
+        yr = s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + eps) * gf + bf
+    else:
+        mu = s.mean(-1, keepdim=True)
+        yr = (s - mu) * torch.rsqrt((s - mu).pow(2).mean(-1, keepdim=True) + eps) * gf + bf
+    gr = torch.autograd.grad(yr, [xf, gf, bf] + ([rf] if rf is not None else []), go.float())
+    errs = [metric(y.detach().float(), yr.detach())] + [metric(a.float(), b) for a, b in zip(gs, gr)]
+    # dgamma / dbeta sum `rows` bf16-rounded products: allow the sqrt(rows) growth of that rounding
+    lims = [lim, lim, lim * max(1.0, rows ** 0.5 / 8), lim * max(1.0, rows ** 0.5 / 8), lim]
+    if any(not np.isfinite(e) or e > l for e, l in zip(errs, lims)):
+        bad += 1
+        print('case %d: %s %s rows=%d C=%d eps=%g errs(y, dx, dgamma, dbeta[, dres]) = %s'
+              % (it, kind, name, rows, C, eps, ['%.3g' % e for e in errs]), flush=True)
+    # masked softmax over a random (B, H, Lq, Lm) with a broadcast mask
+    B, H, Lq, Lm = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 70)), int(rng.integers(1, 300))
+    sc = torch.tensor(rng.standard_normal((B, H, Lq, Lm)) * 3, device='cuda').to(dtype)
+    mk = torch.tensor(rng.random((B, 1, Lq, Lm)) < 0.7, device='cuda')
+    t = float(rng.choice([1.0, 8.0]))
+    w = ac.masked_softmax(sc, mk, axis=-1, temperature=t).float()
+    z = torch.where(mk, sc.float() / t, torch.tensor(float('-inf'), device='cuda'))
+    wr = torch.nan_to_num(torch.softmax(z, -1), 0.0) * mk
+    e = float((w - wr).abs().max())
+    if not np.isfinite(e) or e > (1e-2 if dtype == torch.bfloat16 else 1e-5):
+        bad += 1
+        print('case %d: masked_softmax %s B=%d H=%d Lq=%d Lm=%d t=%g err=%.3g' % (it, name, B, H, Lq, Lm, t, e),
+              flush=True)
+print('%d cases, %d flagged' % (ncase, bad))
