@@ -234,6 +234,7 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     if (mask) { fa.ms[0] = ms[0]; fa.ms[1] = ms[1]; fa.ms[2] = ms[2]; }
     fa.vl = vl; fa.vl_dtype = vl_dtype;
     fa.causal = (!mask && d->causal) ? 1 : 0;
+    fa.vl_pair = (!mask && vl && d->mem_lengths) ? 1 : 0;
     fa.bias = edge;
     if (edge) for (int i = 0; i < 4; ++i) fa.bs[i] = es[i];
     if (edge && edge_f32 && !mask && !fa.causal && (uintptr_t)edge_f32 % 4 == 0) {
@@ -248,6 +249,9 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     return check_launch("fused attention");
   }
   if (cu) return fail(GNLP_ERR_UNSUPPORTED, "packed batches need the fused bf16 attention kernel");
+  if (!mask && vl && d->mem_lengths)
+    return fail(GNLP_ERR_UNSUPPORTED, "only the fused bf16 attention kernel evaluates the memory-"
+                "mask predicate (two lengths per sequence): pass the byte mask");
   if (lse)
     return fail(GNLP_ERR_UNSUPPORTED, "only the fused bf16 attention kernel (bf16, dk = dv = 64, "
                 "16-byte aligned rows) writes the row statistics");
@@ -689,6 +693,9 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
   REQUIRE(d->B * d->H <= 0x7fffffffLL, "batch*heads too large");
   REQUIRE(!(mask && d->causal), "d->causal selects the in-kernel predicate: mask must be NULL");
+  REQUIRE(!d->mem_lengths || (!mask && !d->causal && valid_length),
+          "d->mem_lengths selects the memory-mask predicate: mask NULL, not causal, valid_length "
+          "with 2 B entries");
   if (d->B * d->H * d->Lq * d->dv == 0) return GNLP_OK;
   REQUIRE(ctx && q && k && v, "NULL tensor");
   return attn_impl(ctx, scores_out, weights_out, q, k, v, d, dtype, mask, mask_stride,
@@ -714,6 +721,9 @@ int gnlp_multi_head_dot_attn_lse(void *ctx, void *ctx_lo, float *lse, const void
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
   REQUIRE(d->B * d->H <= 0x7fffffffLL, "batch*heads too large");
   REQUIRE(!(mask && d->causal), "d->causal selects the in-kernel predicate: mask must be NULL");
+  REQUIRE(!d->mem_lengths || (!mask && !d->causal && valid_length),
+          "d->mem_lengths selects the memory-mask predicate: mask NULL, not causal, valid_length "
+          "with 2 B entries");
   if (d->B * d->H * d->Lq * d->dv == 0 || d->Lm == 0 || d->dk == 0)
     return fail(GNLP_ERR_UNSUPPORTED, "empty axis: use gnlp_multi_head_dot_attn");
   REQUIRE(ctx && q && k && v, "NULL tensor");
@@ -748,6 +758,8 @@ int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edg
           "d_edge needs edge_scores, its strides and its element count");
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
   REQUIRE(!(mask && d->causal), "d->causal selects the in-kernel predicate: mask must be NULL");
+  REQUIRE(!d->mem_lengths, "the backward kernels do not evaluate the memory-mask predicate: pass "
+          "the byte mask");
   hipStream_t s = S(stream);
   if (d_edge && d_edge_elems > 0) {
     hipError_t e = hipMemsetAsync(d_edge, 0, (size_t)d_edge_elems * sizeof(float), s);

@@ -82,6 +82,10 @@ attn_fwd_bf16_d64(FusedAttn a) {
       int64_t n = load_len(a.vl, a.vl_dtype, b);
       n = n < 0 ? 0 : n;
       kv_len = n < a.Lm ? n : a.Lm;
+      if (a.vl_pair) {   // memory mask: the queries have their own lengths
+        n = load_len(a.vl, a.vl_dtype, a.B + b);
+        n = n < 0 ? 0 : n;
+      }
       q_valid = n < a.Lq ? n : a.Lq;
     }
     // key tiles entirely above the diagonal of this block's last row are never staged

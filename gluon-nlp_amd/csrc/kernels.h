@@ -164,6 +164,8 @@ struct FusedAttn {
   const void *vl;                       // or null (predicate i<vl && j<vl)
   int vl_dtype;
   int causal;                           // mask null: predicate (j <= i) && (i < vl) instead
+  int vl_pair;                          // vl holds 2 B entries: key lengths, then query lengths
+                                        // (gen_mem_attn_mask): predicate (j < vl[b]) && (i < vl[B + b])
   const int32_t *cu;                    // or null; packed ragged batch: sequence b holds token rows
                                         // cu[b] .. cu[b] + vl[b] - 1 (vl required, batch strides 0)
   const void *bias;                     // edge scores (bf16) or null
@@ -210,6 +212,8 @@ struct GenAttn {
   const void *vl;                       // or null (predicate i<vl && j<vl, used when mask is null)
   int vl_dtype;
   int causal;                           // mask null: predicate (j <= i) && (i < vl) instead
+  int vl_pair;                          // vl holds 2 B entries: key lengths, then query lengths
+                                        // (gen_mem_attn_mask): predicate (j < vl[b]) && (i < vl[B + b])
   const void *bias;                     // edge scores (tensor dtype) or null
   int64_t bs[4];                        // (b, h, i, j)
   float inv_temperature;

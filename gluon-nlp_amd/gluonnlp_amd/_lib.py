@@ -28,7 +28,8 @@ class AttnDesc(Structure):
     _fields_ = [('B', c_int64), ('H', c_int64), ('Lq', c_int64), ('Lm', c_int64),
                 ('dk', c_int64), ('dv', c_int64),
                 ('q_stride', c_int64 * 3), ('k_stride', c_int64 * 3),
-                ('v_stride', c_int64 * 3), ('o_stride', c_int64 * 3), ('causal', c_int64)]
+                ('v_stride', c_int64 * 3), ('o_stride', c_int64 * 3), ('causal', c_int64),
+                ('mem_lengths', c_int64)]
 
 
 class AttnGradDesc(Structure):

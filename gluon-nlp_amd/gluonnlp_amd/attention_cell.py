@@ -38,15 +38,17 @@ def _tag(mask, vl, kind):
     return mask
 
 
-def mask_predicate(mask, causal=False):
-    """-> (kind, valid_length) if ``mask`` is an unmodified product of gen_self_attn_mask, else
-    None.  kind: 'full' ((i < vl) & (j < vl)), 'ones' (no valid_length), and -- only for callers
-    that pass ``causal=True`` because they can evaluate it -- 'causal' ((j <= i) & (i < vl),
-    valid_length possibly None); every other caller sees an untagged mask and reads its bytes."""
+def mask_predicate(mask, causal=False, mem=False):
+    """-> (kind, valid_length) if ``mask`` is an unmodified product of gen_self_attn_mask (or,
+    for callers that pass ``mem=True``, of gen_mem_attn_mask), else None.  kind: 'full'
+    ((i < vl) & (j < vl)), 'ones' (no valid_length), -- only for callers that pass ``causal=True``
+    because they can evaluate it -- 'causal' ((j <= i) & (i < vl), valid_length possibly None), and
+    'mem' ((j < vl[b]) & (i < vl[B + b]): 2 B lengths, keys then queries); every other caller sees
+    an untagged mask and reads its bytes."""
     kind = getattr(mask, '_gnlp_kind', None)
     if kind is None or getattr(mask, '_gnlp_version', -1) != mask._version:
         return None
-    if kind == 'causal' and not causal:
+    if (kind == 'causal' and not causal) or (kind == 'mem' and not mem):
         return None
     return kind, getattr(mask, '_gnlp_vl', None)
 
@@ -90,6 +92,12 @@ def gen_mem_attn_mask(mem, mem_valid_length, data, data_valid_length=None, dtype
     mask = torch.empty((B, Lq, Lm), dtype=torch.bool, device=dev)
     _lib.check(_lib.load().gnlp_gen_mem_attn_mask(T.ptr(mask), mp, dp, mc, B, Lq, Lm,
                                                   T.stream(dev)))
+    # the fused attention kernel can evaluate this mask from the two length vectors
+    if mvl is not None:
+        lengths = torch.cat([mvl.reshape(-1), dvl.reshape(-1) if dvl is not None
+                             else torch.full_like(mvl.reshape(-1), Lq)])
+        _tag(mask, None, 'mem')
+        mask._gnlp_vl = lengths      # (already a private tensor)
     return mask
 
 
@@ -206,6 +214,7 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
         d = _lib.AttnDesc()
         d.B, d.H, d.Lq, d.Lm, d.dk, d.dv = B, H, Lq, Lm, dk, dv
         d.causal = int(causal)
+        d.mem_lengths = 0
         d.q_stride[:] = _bht_strides(q, layout)
         d.k_stride[:] = _bht_strides(k, layout)
         d.v_stride[:] = _bht_strides(v, layout)
@@ -217,9 +226,16 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
 
     mptr, ms = None, None
     causal = False
+    mem_vl = None          # gen_mem_attn_mask's two length vectors, when the fused kernel may use them
     if m is not None:
         # (the causal predicate lives in the kernels for head dims <= 128)
-        pred = mask_predicate(m, causal=dk <= 128 and dv <= 128) if _valid_length is None else None
+        pred = mask_predicate(m, causal=dk <= 128 and dv <= 128, mem=True) \
+            if _valid_length is None else None
+        if pred is not None and pred[0] == 'mem':
+            if (m.shape == (B, Lq, Lm) and not _need_scores and not _need_weights
+                    and q.dtype == torch.bfloat16 and dk == 64 and dv == 64):
+                mem_vl = pred[1]
+            pred = None
         if pred is not None and m.shape == (B, Lq, Lm) and Lq == Lm:
             # the mask came straight from gen_self_attn_mask: evaluate the predicate in-kernel
             kind, pvl = pred
@@ -253,6 +269,17 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
         scores = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_scores else None
         weights = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_weights else None
         lib = _lib.load()
+        if mem_vl is not None and not want_lse:
+            # decoder memory mask on the fused kernel: the predicate from the two length vectors
+            # instead of (B, Lq, Lm) bytes per head (padded keys are skipped, too)
+            d.mem_lengths = 1
+            pvl, pp, pc = T.valid_length_arg(mem_vl)
+            rc = lib.gnlp_multi_head_dot_attn(
+                T.ptr(ctx), None, None, T.ptr(q), T.ptr(k), T.ptr(v), ctypes.byref(d), T.code(q),
+                None, None, pp, pc, eptr, es, temperature, None, 0, T.stream(dev))
+            if rc == 0:
+                return ctx, None, None
+            d.mem_lengths = 0            # (alignment: another kernel serves the call) -> mask bytes
         if want_lse:
             # (scaled attention only: with raw scores -- T5 -- the softmax is peaked, dP - D cancels
             # hard, and D = <dO, ctx> inherits the bf16 rounding of P inside ctx: measured tails of

@@ -172,6 +172,12 @@ typedef struct {
                      gen_self_attn_mask(attn_type='causal')'s (attention_cell.py:168-180),
                      (j <= i) & (i < valid_length[b]) -- valid_length may be NULL (lower triangle);
                      key tiles above the diagonal are skipped */
+  int64_t mem_lengths; /* != 0 (mask NULL, not causal, valid_length given): valid_length holds
+                     2 B entries, the key lengths and then the query lengths, and the in-kernel
+                     predicate is gen_mem_attn_mask's (attention_cell.py:186-274),
+                     (j < valid_length[b]) & (i < valid_length[B + b]).  Only the fused bf16 kernel
+                     evaluates it: GNLP_ERR_UNSUPPORTED otherwise (pass the byte mask); not
+                     accepted by the backward entry point */
 } gnlp_attn_desc;
 
 size_t gnlp_attn_workspace_bytes(const gnlp_attn_desc *d, int dtype, int want_scores,

@@ -2,6 +2,7 @@
 the BERT / RoBERTa / ELECTRA / TransformerEncoder stacks and the T5 encoder, against the committed
 golden fixtures (generated from the reference's torch sibling) and the CPU oracle.
 fp32 within 1e-5, bf16 within 2e-2 (max-abs relative); masks / zeros exact."""
+import ctypes
 import os
 
 import numpy as np
@@ -689,3 +690,59 @@ def test_fused_attention_max_over_both_lane_halves(nlp, case):
         ctx2, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged, None, scaled=scaled, query_head_units=d,
                                          layout='NTK', _need_scores=False, _need_weights=False)
         assert np.isfinite(to_np(ctx2)).all() and rel_err(to_np(ctx2), ectx) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_data_vl', [False, True])
+@pytest.mark.parametrize('Lq,Lm', [(70, 200), (256, 512), (1, 33)])
+def test_fused_attention_memory_mask_predicate(nlp, with_data_vl, Lq, Lm):
+    """Decoder cross-attention: a mask straight from gen_mem_attn_mask is evaluated in the fused
+    kernel from its two length vectors ((j < mem_vl[b]) & (i < data_vl[b]), attention_cell.py:
+    186-274) -- bit for bit the output of the same bytes handed over untagged, and the oracle's;
+    in-place edits of the mask or of the callers' length tensors do not change what is computed
+    from the bytes."""
+    ac = nlp.attention_cell
+    B, H, d = 3, 2, 64
+    rng = np.random.default_rng(Lq + Lm)
+    q = rng.standard_normal((B, H, Lq, d))
+    k, v = rng.standard_normal((B, H, Lm, d)), rng.standard_normal((B, H, Lm, d))
+    mem_vl = np.array([Lm, 1, max(1, Lm * 2 // 3)])
+    data_vl = np.array([Lq, max(1, Lq // 2), 1]) if with_data_vl else None
+    qq, kk, vv = [to_dev(np.transpose(x, (0, 2, 1, 3)), torch.bfloat16) for x in (q, k, v)]
+    mvl_t = torch.tensor(mem_vl, device='cuda')
+    dvl_t = torch.tensor(data_vl, device='cuda') if with_data_vl else None
+    mem = torch.zeros((B, Lm, 1), device='cuda')
+    data = torch.zeros((B, Lq, 1), device='cuda')
+    tagged = ac.gen_mem_attn_mask(mem, mvl_t, data, dvl_t)
+    mask_np = ref.gen_mem_attn_mask((B, Lm), mem_vl, (B, Lq), data_vl)
+    assert np.array_equal(to_np(tagged).astype(bool), mask_np.astype(bool))
+    assert ac.mask_predicate(tagged) is None and ac.mask_predicate(tagged, mem=True)[0] == 'mem'
+    dense = tagged.clone()
+    kw = dict(scaled=True, query_head_units=d, layout='NTK', _need_scores=False, _need_weights=False)
+    a, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged, None, **kw)
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_FUSED_BF16
+    b, _ = ac.multi_head_dot_attn(qq, kk, vv, dense, None, **kw)
+    assert torch.equal(a, b)
+    ectx, _ = ref.multi_head_dot_attn(prep(q, torch.bfloat16), prep(k, torch.bfloat16),
+                                      prep(v, torch.bfloat16), mask_np, None, query_head_units=d)
+    assert rel_err(to_np(a), ectx) < 2e-2
+    # the callers' length tensors edited in place afterwards: the tag holds its own copy
+    mvl_t.fill_(1)
+    c, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged, None, **kw)
+    assert torch.equal(a, c)
+    # the mask edited in place: the tag is void, the bytes rule
+    tagged[:, :, 0] = False
+    assert ac.mask_predicate(tagged, mem=True) is None
+    e, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged, None, **kw)
+    f, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged.clone(), None, **kw)
+    assert torch.equal(e, f)
+    # the C ABI refuses the pair-of-lengths predicate where no kernel evaluates it
+    dd = _lib.AttnDesc()
+    dd.B, dd.H, dd.Lq, dd.Lm, dd.dk, dd.dv = 1, 1, 4, 4, 8, 8
+    dd.mem_lengths = 1
+    x = torch.zeros(64, device='cuda')
+    two = torch.tensor([4, 4], device='cuda', dtype=torch.int32)
+    rc = _lib.load().gnlp_multi_head_dot_attn(x.data_ptr(), None, None, x.data_ptr(), x.data_ptr(),
+                                              x.data_ptr(), ctypes.byref(dd), _lib.F32, None, None,
+                                              two.data_ptr(), _lib.I32, None, None, 1.0, None, 0, None)
+    assert rc == -2 and b'memory-mask' in _lib.load().gnlp_last_error()
