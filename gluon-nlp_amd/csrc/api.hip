@@ -249,9 +249,6 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     return check_launch("fused attention");
   }
   if (cu) return fail(GNLP_ERR_UNSUPPORTED, "packed batches need the fused bf16 attention kernel");
-  if (!mask && vl && d->mem_lengths)
-    return fail(GNLP_ERR_UNSUPPORTED, "only the fused bf16 attention kernel evaluates the memory-"
-                "mask predicate (two lengths per sequence): pass the byte mask");
   if (lse)
     return fail(GNLP_ERR_UNSUPPORTED, "only the fused bf16 attention kernel (bf16, dk = dv = 64, "
                 "16-byte aligned rows) writes the row statistics");
@@ -269,6 +266,7 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
     if (mask) { ga.ms[0] = ms[0]; ga.ms[1] = ms[1]; ga.ms[2] = ms[2]; }
     ga.vl = vl; ga.vl_dtype = vl_dtype;
     ga.causal = (!mask && d->causal) ? 1 : 0;
+    ga.vl_pair = (!mask && vl && d->mem_lengths) ? 1 : 0;
     ga.bias = edge;
     if (edge) for (int i = 0; i < 4; ++i) ga.bs[i] = es[i];
     ga.inv_temperature = inv_t;
@@ -281,6 +279,10 @@ int attn_impl(void *ctx, void *scores_out, void *weights_out, const void *q, con
   if (!mask && d->causal)
     return fail(GNLP_ERR_UNSUPPORTED, "the in-kernel causal predicate needs head dims <= 128 "
                 "(dk=%lld dv=%lld): pass the byte mask", (long long)d->dk, (long long)d->dv);
+  if (!mask && vl && d->mem_lengths)
+    return fail(GNLP_ERR_UNSUPPORTED, "the in-kernel memory-mask predicate (two lengths per "
+                "sequence) needs head dims <= 128 (dk=%lld dv=%lld): pass the byte mask",
+                (long long)d->dk, (long long)d->dv);
   g_attn_kernel = GNLP_ATTN_KERNEL_UNFUSED;
   // ---- unfused path: scores -> masked softmax -> context (attention_cell.py:452-463) ----
   const size_t need = attn_ws_bytes(d, dtype, scores_out != nullptr, weights_out != nullptr, false);
@@ -758,8 +760,9 @@ int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edg
           "d_edge needs edge_scores, its strides and its element count");
   REQUIRE(!valid_length || vl_ok(vl_dtype), "bad valid_length dtype %d", vl_dtype);
   REQUIRE(!(mask && d->causal), "d->causal selects the in-kernel predicate: mask must be NULL");
-  REQUIRE(!d->mem_lengths, "the backward kernels do not evaluate the memory-mask predicate: pass "
-          "the byte mask");
+  REQUIRE(!d->mem_lengths || (!mask && !d->causal && valid_length),
+          "d->mem_lengths selects the memory-mask predicate: mask NULL, not causal, valid_length "
+          "= 2 B lengths");
   hipStream_t s = S(stream);
   if (d_edge && d_edge_elems > 0) {
     hipError_t e = hipMemsetAsync(d_edge, 0, (size_t)d_edge_elems * sizeof(float), s);
@@ -790,6 +793,7 @@ int gnlp_multi_head_dot_attn_backward(void *dq, void *dk, void *dv, float *d_edg
   a.vl = mask ? nullptr : valid_length;
   a.vl_dtype = vl_dtype;
   a.causal = (!mask && d->causal) ? 1 : 0;
+  a.vl_pair = (a.vl && d->mem_lengths) ? 1 : 0;
   a.bias = edge_scores;
   a.inv_temperature = temperature > 0.0f ? 1.0f / temperature : 1.0f;
   REQUIRE((gd->fwd_ctx == nullptr) == (gd->fwd_lse == nullptr) &&

@@ -72,12 +72,9 @@ attn_bwd_q_kernel(GenAttnBwd a) {
   const int64_t qoff = b * a.qs[0] + h * a.qs[1], koff = b * a.ks[0] + h * a.ks[1],
                 voff = b * a.vs[0] + h * a.vs[1], goff = b * a.gs[0] + h * a.gs[1];
 
-  int64_t vlen = -1;
-  if (!a.mask && a.vl) {
-    vlen = load_len(a.vl, a.vl_dtype, b);
-    vlen = vlen < 0 ? 0 : vlen;
-  }
-  const bool row_on = vlen < 0 || my_q < vlen;
+  int64_t vlen = -1, qlen = -1;   // valid keys / valid queries
+  if (!a.mask && a.vl) load_len_pair(a.vl, a.vl_dtype, a.vl_pair, a.B, b, vlen, qlen);
+  const bool row_on = qlen < 0 || my_q < qlen;
 
   float qf[D / 2], gf[D / 2];
   {
@@ -297,11 +294,8 @@ attn_bwd_kv_kernel(GenAttnBwd a) {
   const int64_t qoff = b * a.qs[0] + h * a.qs[1], koff = b * a.ks[0] + h * a.ks[1],
                 voff = b * a.vs[0] + h * a.vs[1], goff = b * a.gs[0] + h * a.gs[1];
 
-  int64_t vlen = -1;
-  if (!a.mask && a.vl) {
-    vlen = load_len(a.vl, a.vl_dtype, b);
-    vlen = vlen < 0 ? 0 : vlen;
-  }
+  int64_t vlen = -1, qlen = -1;   // valid keys / valid queries
+  if (!a.mask && a.vl) load_len_pair(a.vl, a.vl_dtype, a.vl_pair, a.B, b, vlen, qlen);
   const bool col_on = my_k < a.Lm && (vlen < 0 || my_k < vlen);
 
   float kf[D / 2], vf[D / 2];
@@ -382,7 +376,7 @@ attn_bwd_kv_kernel(GenAttnBwd a) {
         if (on) {
           if (a.bias) x += ldf<T>(a.bias, b * a.bs[0] + h * a.bs[1] + i * a.bs[2] + my_k * a.bs[3]);
           if (a.mask) on = a.mask[b * a.ms[0] + i * a.ms[1] + my_k * a.ms[2]] != 0;
-          else on = (vlen < 0 || i < vlen) && (!a.causal || my_k <= i);
+          else on = (qlen < 0 || i < qlen) && (!a.causal || my_k <= i);
         }
         p[e] = on ? __expf(x * inv_t - Ls[r]) : 0.0f;
         ds[e] = p[e] * (dpacc[e] - Ds[r]) * inv_t;

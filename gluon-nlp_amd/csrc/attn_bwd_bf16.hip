@@ -212,16 +212,13 @@ attn_bwd_q_bf16_kernel(GenAttnBwd a) {
   const bf16 *vg = (const bf16 *)a.v + b * a.vs[0] + h * a.vs[1];
   const bf16 *gg = (const bf16 *)a.g + b * a.gs[0] + h * a.gs[1];
 
-  int64_t vlen = -1;
-  if (!a.mask && a.vl) {
-    vlen = load_len(a.vl, a.vl_dtype, b);
-    vlen = vlen < 0 ? 0 : vlen;
-  }
+  int64_t vlen = -1, qlen = -1;   // valid keys / valid queries
+  if (!a.mask && a.vl) load_len_pair(a.vl, a.vl_dtype, a.vl_pair, a.B, b, vlen, qlen);
   const bool gen = a.bias != nullptr || a.mask != nullptr;   // uniform: per-element bias / mask
   // without a dense mask: key j of this lane's query is on iff j < klim
   const int lim = (int)((vlen >= 0 && vlen < a.Lm) ? vlen : a.Lm);
   int klim = 0;
-  if (my_q < a.Lq && (vlen < 0 || my_q < vlen))
+  if (my_q < a.Lq && (qlen < 0 || my_q < qlen))
     klim = (a.causal && my_q + 1 < lim) ? (int)(my_q + 1) : lim;
 
   bf16x8 qf[4], gf[4];   // B operands: query my_q, head dims 16 s + 8 hh .. + 7
@@ -436,15 +433,12 @@ attn_bwd_kv_bf16_kernel(GenAttnBwd a) {
   const bf16 *vg = (const bf16 *)a.v + b * a.vs[0] + h * a.vs[1];
   const bf16 *gg = (const bf16 *)a.g + b * a.gs[0] + h * a.gs[1];
 
-  int64_t vlen = -1;
-  if (!a.mask && a.vl) {
-    vlen = load_len(a.vl, a.vl_dtype, b);
-    vlen = vlen < 0 ? 0 : vlen;
-  }
+  int64_t vlen = -1, qlen = -1;   // valid keys / valid queries
+  if (!a.mask && a.vl) load_len_pair(a.vl, a.vl_dtype, a.vl_pair, a.B, b, vlen, qlen);
   const bool gen = a.bias != nullptr || a.mask != nullptr || a.de != nullptr;   // uniform
   const bool col_on = my_k < a.Lm && (vlen < 0 || my_k < vlen);
   // without a dense mask: query i is on for this lane's key iff qlo <= i < qhi
-  const int qlim = (int)((vlen >= 0 && vlen < a.Lq) ? vlen : a.Lq);
+  const int qlim = (int)((qlen >= 0 && qlen < a.Lq) ? qlen : a.Lq);
   const int qhi = col_on ? qlim : 0;
   const int qlo = a.causal ? (int)my_k : 0;
 

@@ -72,12 +72,11 @@ attn_gen_kernel(GenAttn a) {
   const int64_t qoff = b * a.qs[0] + h * a.qs[1], koff = b * a.ks[0] + h * a.ks[1],
                 voff = b * a.vs[0] + h * a.vs[1];
 
-  int64_t vlen = -1;   // valid_length predicate (i < vl[b]) & (j < vl[b]) when no dense mask
-  if (!a.mask && a.vl) {
-    vlen = load_len(a.vl, a.vl_dtype, b);
-    vlen = vlen < 0 ? 0 : vlen;
-  }
-  const bool row_on = vlen < 0 || my_q < vlen;
+  // valid_length predicate (i < qlen) & (j < vlen) when no dense mask (qlen = vlen = vl[b] for a
+  // self-attention mask, two lengths for a memory mask)
+  int64_t vlen = -1, qlen = -1;
+  if (!a.mask && a.vl) load_len_pair(a.vl, a.vl_dtype, a.vl_pair, a.B, b, vlen, qlen);
+  const bool row_on = qlen < 0 || my_q < qlen;
 
   // ---- Q fragments: qf[s] = Q[my_q][hh * D/2 + s] (zero beyond d_k / Lq) ----
   float qf[D / 2];

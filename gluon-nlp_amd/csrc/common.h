@@ -58,6 +58,21 @@ __device__ __forceinline__ int64_t load_len(const void *p, int vl_dtype, int64_t
   return vl_dtype == GNLP_I64 ? ((const int64_t *)p)[i] : (int64_t)((const int32_t *)p)[i];
 }
 
+// The lengths behind the in-kernel predicates of sequence b when no dense mask is given:
+// klen = valid keys, qlen = valid queries (-1: no lengths, everything is on).  gen_self_attn_mask
+// products have one length per sequence; gen_mem_attn_mask products (pair != 0) hold B memory
+// lengths followed by B query lengths (attention_cell.py:153-161, :262-272).
+__device__ __forceinline__ void load_len_pair(const void *p, int vl_dtype, int pair, int64_t B,
+                                              int64_t b, int64_t &klen, int64_t &qlen) {
+  klen = load_len(p, vl_dtype, b);
+  klen = klen < 0 ? 0 : klen;
+  qlen = klen;
+  if (pair) {
+    qlen = load_len(p, vl_dtype, B + b);
+    qlen = qlen < 0 ? 0 : qlen;
+  }
+}
+
 // layers.py:236-338.  EXACT selects erff (fp32 tolerance path); the bf16 path may use the
 // cheaper rational erf (|err| < 1.5e-7, far below bf16 resolution).
 __device__ __forceinline__ float erf_fast(float x) {

@@ -235,6 +235,7 @@ struct GenAttnBwd {
   const void *vl;
   int vl_dtype;
   int causal;
+  int vl_pair;                          // as GenAttn::vl_pair
   const void *bias;
   int64_t bs[4];
   float inv_temperature;

@@ -214,7 +214,7 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
         d = _lib.AttnDesc()
         d.B, d.H, d.Lq, d.Lm, d.dk, d.dv = B, H, Lq, Lm, dk, dv
         d.causal = int(causal)
-        d.mem_lengths = 0
+        d.mem_lengths = int(mem)
         d.q_stride[:] = _bht_strides(q, layout)
         d.k_stride[:] = _bht_strides(k, layout)
         d.v_stride[:] = _bht_strides(v, layout)
@@ -226,22 +226,19 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
 
     mptr, ms = None, None
     causal = False
-    mem_vl = None          # gen_mem_attn_mask's two length vectors, when the fused kernel may use them
+    mem = False            # gen_mem_attn_mask's predicate: valid_length = B key + B query lengths
     if m is not None:
-        # (the causal predicate lives in the kernels for head dims <= 128)
-        pred = mask_predicate(m, causal=dk <= 128 and dv <= 128, mem=True) \
-            if _valid_length is None else None
-        if pred is not None and pred[0] == 'mem':
-            if (m.shape == (B, Lq, Lm) and not _need_scores and not _need_weights
-                    and q.dtype == torch.bfloat16 and dk == 64 and dv == 64):
-                mem_vl = pred[1]
-            pred = None
-        if pred is not None and m.shape == (B, Lq, Lm) and Lq == Lm:
-            # the mask came straight from gen_self_attn_mask: evaluate the predicate in-kernel
+        # (the causal and memory predicates live in the kernels for head dims <= 128)
+        small = dk <= 128 and dv <= 128
+        pred = mask_predicate(m, causal=small, mem=small) if _valid_length is None else None
+        if pred is not None and m.shape == (B, Lq, Lm) and (Lq == Lm or pred[0] == 'mem'):
+            # the mask came straight from gen_self_attn_mask / gen_mem_attn_mask: evaluate the
+            # predicate in-kernel
             kind, pvl = pred
-            if kind in ('full', 'causal') and pvl is not None:
+            if kind in ('full', 'causal', 'mem') and pvl is not None:
                 vlt, vlp, vlc = T.valid_length_arg(pvl)
             causal = kind == 'causal'
+            mem = kind == 'mem'
             m = None
         else:
             if m.dtype != torch.bool:
@@ -269,17 +266,6 @@ def multi_head_dot_attn(query, key, value, mask=None, edge_scores=None, dropout:
         scores = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_scores else None
         weights = torch.empty((B, H, Lq, Lm), dtype=q.dtype, device=dev) if _need_weights else None
         lib = _lib.load()
-        if mem_vl is not None and not want_lse:
-            # decoder memory mask on the fused kernel: the predicate from the two length vectors
-            # instead of (B, Lq, Lm) bytes per head (padded keys are skipped, too)
-            d.mem_lengths = 1
-            pvl, pp, pc = T.valid_length_arg(mem_vl)
-            rc = lib.gnlp_multi_head_dot_attn(
-                T.ptr(ctx), None, None, T.ptr(q), T.ptr(k), T.ptr(v), ctypes.byref(d), T.code(q),
-                None, None, pp, pc, eptr, es, temperature, None, 0, T.stream(dev))
-            if rc == 0:
-                return ctx, None, None
-            d.mem_lengths = 0            # (alignment: another kernel serves the call) -> mask bytes
         if want_lse:
             # (scaled attention only: with raw scores -- T5 -- the softmax is peaked, dP - D cancels
             # hard, and D = <dO, ctx> inherits the bf16 rounding of P inside ctx: measured tails of

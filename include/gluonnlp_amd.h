@@ -175,9 +175,9 @@ typedef struct {
   int64_t mem_lengths; /* != 0 (mask NULL, not causal, valid_length given): valid_length holds
                      2 B entries, the key lengths and then the query lengths, and the in-kernel
                      predicate is gen_mem_attn_mask's (attention_cell.py:186-274),
-                     (j < valid_length[b]) & (i < valid_length[B + b]).  Only the fused bf16 kernel
-                     evaluates it: GNLP_ERR_UNSUPPORTED otherwise (pass the byte mask); not
-                     accepted by the backward entry point */
+                     (j < valid_length[b]) & (i < valid_length[B + b]), in the forward and
+                     backward kernels (head dims <= 128; GNLP_ERR_UNSUPPORTED beyond: pass the
+                     byte mask) */
 } gnlp_attn_desc;
 
 size_t gnlp_attn_workspace_bytes(const gnlp_attn_desc *d, int dtype, int want_scores,

@@ -133,6 +133,43 @@ def test_attention_backward_valid_length_predicate(nlp, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('Lq,Lm,d,fused', [(70, 130, 64, True), (70, 130, 64, False), (33, 200, 24, False),
+                                           (130, 40, 64, True)])
+def test_attention_backward_memory_mask_predicate(nlp, dtype, Lq, Lm, d, fused):
+    """A mask straight from gen_mem_attn_mask is evaluated as (j < mem_vl[b]) & (i < data_vl[b])
+    in the backward kernels too (general fp32-MFMA pair, bf16-MFMA pair, with and without the
+    fused forward's saved statistics): the gradients of the dense bytes and of the float64 oracle;
+    switched-off keys and query rows take no gradient."""
+    ac = nlp.attention_cell
+    B, H = 3, 2
+    rng = np.random.default_rng(Lq * 7 + Lm + d)
+    q, k, v = (rng.standard_normal((B, H, Lq, d)), rng.standard_normal((B, H, Lm, d)),
+               rng.standard_normal((B, H, Lm, d)))
+    gc = rng.standard_normal((B, Lq, H * d))
+    e = rng.standard_normal((H, Lq, Lm))
+    mem_vl, data_vl = np.array([Lm, 1, Lm * 2 // 3]), np.array([Lq // 2, Lq, 1])
+    tagged = ac.gen_mem_attn_mask(torch.zeros((B, Lm, 1), device='cuda'), torch.tensor(mem_vl, device='cuda'),
+                                  torch.zeros((B, Lq, 1), device='cuda'), torch.tensor(data_vl, device='cuda'))
+    assert ac.mask_predicate(tagged, mem=True)[0] == 'mem'
+    kw = dict(_need_scores=False, _need_weights=False) if fused else {}
+    a = run_attn(ac, 'NTK', (0, 2, 1, 3), q, k, v, tagged, e, gc, True, dtype, d, **kw)
+    b = run_attn(ac, 'NTK', (0, 2, 1, 3), q, k, v, tagged.clone(), e, gc, True, dtype, d, **kw)
+    mask_np = ref.gen_mem_attn_mask((B, Lm), mem_vl, (B, Lq), data_vl).astype(bool)
+    pq, pk, pv, pg, pe = [prep(x, dtype) for x in (q, k, v, gc, e)]
+    want = [ref.multi_head_dot_attn(pq, pk, pv, mask_np, pe, scaled=True, query_head_units=d)[0]] + \
+        list(ref.multi_head_dot_attn_backward(pg, pq, pk, pv, mask_np, pe, scaled=True,
+                                              query_head_units=d))
+    t = 1e-5 if dtype == torch.float32 else 3e-2
+    for name, x, y, w in zip(('ctx', 'dq', 'dk', 'dv', 'de'), a, b, want):
+        assert np.isfinite(x).all(), name
+        assert rel_err(x, y) < t, name
+        assert rel_err(x, w) < t, name
+    for bb in range(B):
+        assert (a[1][bb, :, data_vl[bb]:] == 0).all()            # dq of padded queries
+        assert (a[2][bb, :, mem_vl[bb]:] == 0).all() and (a[3][bb, :, mem_vl[bb]:] == 0).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,H,Lq,Lm,dk,dv,eshape', [
     (2, 3, 70, 130, 96, 128, 'bh'),      # 128-wide template, cross attention, ragged tiles
     (1, 2, 33, 31, 20, 32, '1h'),        # 32-wide template, bias shared over the batch (T5)

@@ -736,13 +736,56 @@ def test_fused_attention_memory_mask_predicate(nlp, with_data_vl, Lq, Lm):
     e, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged, None, **kw)
     f, _ = ac.multi_head_dot_attn(qq, kk, vv, tagged.clone(), None, **kw)
     assert torch.equal(e, f)
-    # the C ABI refuses the pair-of-lengths predicate where no kernel evaluates it
+    # the C ABI refuses the pair-of-lengths predicate where no kernel evaluates it (head dims
+    # beyond 128), and with a mask or the causal flag beside it
+    lib = _lib.load()
     dd = _lib.AttnDesc()
-    dd.B, dd.H, dd.Lq, dd.Lm, dd.dk, dd.dv = 1, 1, 4, 4, 8, 8
+    dd.B, dd.H, dd.Lq, dd.Lm, dd.dk, dd.dv = 1, 1, 4, 4, 256, 256
+    dd.q_stride[:] = dd.k_stride[:] = dd.v_stride[:] = dd.o_stride[:] = [1024, 256, 256]
     dd.mem_lengths = 1
-    x = torch.zeros(64, device='cuda')
+    x = torch.zeros(4096, device='cuda')
     two = torch.tensor([4, 4], device='cuda', dtype=torch.int32)
-    rc = _lib.load().gnlp_multi_head_dot_attn(x.data_ptr(), None, None, x.data_ptr(), x.data_ptr(),
-                                              x.data_ptr(), ctypes.byref(dd), _lib.F32, None, None,
-                                              two.data_ptr(), _lib.I32, None, None, 1.0, None, 0, None)
-    assert rc == -2 and b'memory-mask' in _lib.load().gnlp_last_error()
+    args = lambda m, ms: (x.data_ptr(), None, None, x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                          ctypes.byref(dd), _lib.F32, m, ms, two.data_ptr(), _lib.I32, None, None,
+                          1.0, None, 0, None)
+    assert lib.gnlp_multi_head_dot_attn(*args(None, None)) == -2
+    assert b'memory-mask' in lib.gnlp_last_error()
+    dd.dk = dd.dv = 8
+    dd.causal = 1
+    assert lib.gnlp_multi_head_dot_attn(*args(None, None)) == -1
+    dd.causal = 0
+    mb = torch.ones(16, dtype=torch.bool, device='cuda')
+    assert lib.gnlp_multi_head_dot_attn(*args(mb.data_ptr(), (ctypes.c_int64 * 3)(16, 4, 1))) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['NKT', 'NTK', 'TNK'])
+def test_general_attention_memory_mask_predicate(nlp, layout, dtype):
+    """The same predicate on the general MFMA kernel (fp32, other head dims, scores / weights
+    wanted): the tagged gen_mem_attn_mask product against its untagged bytes and the oracle, with
+    the weights of switched-off keys / rows exactly zero."""
+    ac = nlp.attention_cell
+    B, H, Lq, Lm, dk, dv = 3, 2, 45, 70, 24, 40
+    rng = np.random.default_rng(5)
+    q, k, v = (rng.standard_normal((B, H, Lq, dk)), rng.standard_normal((B, H, Lm, dk)),
+               rng.standard_normal((B, H, Lm, dv)))
+    e = rng.standard_normal((H, Lq, Lm))
+    perm = {'NKT': None, 'NTK': (0, 2, 1, 3), 'TNK': (2, 0, 1, 3)}[layout]
+    qq, kk, vv = [to_dev(x if perm is None else np.transpose(x, perm), dtype) for x in (q, k, v)]
+    mem_vl, data_vl = np.array([Lm, 1, 37]), np.array([11, Lq, 1])
+    tagged = ac.gen_mem_attn_mask(torch.zeros((B, Lm, 1), device='cuda'), torch.tensor(mem_vl, device='cuda'),
+                                  torch.zeros((B, Lq, 1), device='cuda'), torch.tensor(data_vl, device='cuda'))
+    mask_np = ref.gen_mem_attn_mask((B, Lm), mem_vl, (B, Lq), data_vl)
+    kw = dict(scaled=True, query_head_units=dk, layout=layout)
+    a, (sa, wa) = ac.multi_head_dot_attn(qq, kk, vv, tagged, to_dev(e, dtype), **kw)
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_GENERAL_MFMA
+    b, (sb, wb) = ac.multi_head_dot_attn(qq, kk, vv, tagged.clone(), to_dev(e, dtype), **kw)
+    assert torch.equal(a, b) and torch.equal(wa, wb) and torch.equal(sa, sb)
+    off = ~torch.from_numpy(mask_np.astype(bool)).cuda()
+    assert (wa[off[:, None].expand_as(wa)] == 0).all()
+    ectx, (_, ew) = ref.multi_head_dot_attn(prep(q, dtype), prep(k, dtype), prep(v, dtype), mask_np,
+                                            prep(e, dtype), query_head_units=dk)
+    got = to_np(a) if layout != 'TNK' else np.transpose(to_np(a), (1, 0, 2))
+    assert rel_err(got, ectx) < tol(dtype)
+    assert rel_err(to_np(wa), ew) < tol(dtype)
