@@ -30,7 +30,7 @@ for it in range(ncase):
     k = torch.tensor(rng.standard_normal((B, Lm, H, d)), device='cuda').to(torch.bfloat16)
     v = torch.tensor(rng.standard_normal((B, Lm, H, d)), device='cuda').to(torch.bfloat16)
     go = torch.tensor(rng.standard_normal((B, Lq, H * d)), device='cuda').to(torch.bfloat16)
-    kind = rng.choice(['none', 'random', 'upper', 'blocks', 'pred', 'causal'])
+    kind = rng.choice(['none', 'random', 'upper', 'blocks', 'pred', 'causal', 'mem'])
     mask = None
     if kind == 'random':
         mask = torch.tensor(rng.random((B, Lq, Lm)) < rng.choice([0.05, 0.5, 0.95]), device='cuda')
@@ -44,16 +44,27 @@ for it in range(ncase):
         vl = torch.tensor(rng.integers(0, Lq + 1, size=B), device='cuda')
         mask = ac.gen_self_attn_mask(torch.zeros((B, Lq, 1), device='cuda'), vl,
                                      attn_type='full' if kind == 'pred' else 'causal')
+    elif kind == 'mem':
+        mask = ac.gen_mem_attn_mask(torch.zeros((B, Lm, 1), device='cuda'),
+                                    torch.tensor(rng.integers(0, Lm + 1, size=B), device='cuda'),
+                                    torch.zeros((B, Lq, 1), device='cuda'),
+                                    torch.tensor(rng.integers(0, Lq + 1, size=B), device='cuda')
+                                    if rng.random() < 0.7 else None)
     e = None
     if rng.random() < 0.3:
         shape = [(H, Lq, Lm), (B, H, Lq, Lm), (1, 1, Lq, Lm)][int(rng.integers(0, 3))]
         e = torch.tensor(rng.standard_normal(shape), device='cuda').to(torch.bfloat16)
     kw = dict(scaled=bool(rng.random() < 0.7), query_head_units=d, layout='NTK')
     _lib.set_knob('GNLP_ATTN_BWD_BF16', '0')
-    ref = grads(q, k, v, mask, e, go, kw, False)
+    # (a memory mask: the reference reads its untagged bytes, and the fp32-MFMA kernels evaluating
+    # the predicate are checked against that as well)
+    ref = grads(q, k, v, mask.clone() if kind == 'mem' else mask, e, go, kw, False)
+    runs = [(False, grads(q, k, v, mask, e, go, kw, False))] if kind == 'mem' else []
     _lib.set_knob('GNLP_ATTN_BWD_BF16', None)
-    for fused_fwd in (False, True):
-        got = grads(q, k, v, mask, e, go, kw, fused_fwd)
+    runs += [(f, None) for f in (False, True)]
+    for fused_fwd, got in runs:
+        if got is None:
+            got = grads(q, k, v, mask, e, go, kw, fused_fwd)
         for name, a, b in zip(('dq', 'dk', 'dv', 'de'), got, ref):
             fin = bool(torch.isfinite(a).all())
             rms = float(b.pow(2).mean().sqrt()) + 1e-4 * float(go.float().abs().max())

@@ -19,7 +19,7 @@ for it in range(ncase):
     q = torch.tensor(rng.standard_normal((B, Lq, H, d)) * scale, device='cuda').to(torch.bfloat16)
     k = torch.tensor(rng.standard_normal((B, Lm, H, d)) * scale, device='cuda').to(torch.bfloat16)
     v = torch.tensor(rng.standard_normal((B, Lm, H, d)), device='cuda').to(torch.bfloat16)
-    kind = rng.choice(['none', 'random', 'sparse', 'band', 'upper', 'cols', 'blocks', 'pred', 'causal'])
+    kind = rng.choice(['none', 'random', 'sparse', 'band', 'upper', 'cols', 'blocks', 'pred', 'causal', 'mem'])
     mask = None
     if kind == 'random':
         m = rng.random((B, Lq, Lm)) < rng.choice([0.02, 0.5, 0.98])
@@ -49,6 +49,12 @@ for it in range(ncase):
         vl = torch.tensor(rng.integers(0, Lq + 1, size=B), device='cuda')
         mask = ac.gen_self_attn_mask(torch.zeros((B, Lq, 1), device='cuda'), vl,
                                      attn_type='full' if kind == 'pred' else 'causal')
+    elif kind == 'mem':
+        mask = ac.gen_mem_attn_mask(torch.zeros((B, Lm, 1), device='cuda'),
+                                    torch.tensor(rng.integers(0, Lm + 1, size=B), device='cuda'),
+                                    torch.zeros((B, Lq, 1), device='cuda'),
+                                    torch.tensor(rng.integers(0, Lq + 1, size=B), device='cuda')
+                                    if rng.random() < 0.7 else None)
     e = None
     if rng.random() < 0.4:
         shape = [(H, Lq, Lm), (B, H, Lq, Lm), (1, 1, Lq, Lm)][int(rng.integers(0, 3))]
@@ -59,6 +65,12 @@ for it in range(ncase):
     ka = _lib.load().gnlp_attn_last_kernel()
     b, _ = ac.multi_head_dot_attn(q, k, v, mask, e, **kw)
     kb = _lib.load().gnlp_attn_last_kernel()
+    if kind == 'mem':   # the general kernel's predicate against the same mask's untagged bytes
+        c, _ = ac.multi_head_dot_attn(q, k, v, mask.clone(), e, **kw)
+        if not torch.equal(b, c):
+            bad += 1
+            print('case %d: general kernel, memory predicate != bytes (B=%d H=%d Lq=%d Lm=%d)'
+                  % (it, B, H, Lq, Lm), flush=True)
     af, bf = a.float(), b.float()
     ok = bool(torch.isfinite(af).all()) and bool(torch.isfinite(bf).all())
     err = float((af - bf).abs().max() / (bf.abs().max() + 1e-6)) if ok else float('nan')
