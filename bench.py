@@ -304,7 +304,7 @@ def main():
         achieved = kflops / (ms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch of the dominant kernel, from the separate PMC passes
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r02f_hbm_traffic_pmc.json')))
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r02g_hbm_traffic_pmc.json')))
             for k, v in tj.items():
                 if 'dense_bf16_w4' in k and '<2' in k and args.config == 'bert_large' and act == 'gelu':
                     traffic = (v['fetch_MB_corrected_x2'] + v['write_MB']) * 1048576.0
