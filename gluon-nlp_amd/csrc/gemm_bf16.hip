@@ -172,6 +172,107 @@ dense_bf16_kernel(DenseArgs a) {
   }
 }
 
+// ---- a few rows (M <= 64: one decoding step of a batch) ----
+// The tiled kernel above gives such a call N / 128 workgroups, each walking all of K through
+// barriers two 64-wide tiles at a time: 6 workgroups and 19 us for N = K = 768 on a 256-CU chip,
+// for 1.2 MB of weights.  Here a workgroup owns 16 output columns for all rows and its 8 waves
+// split K: every wave streams its share of the weight rows straight from global memory into
+// MFMA fragments (no LDS staging, no barrier in the loop, loads of several k-steps in flight), the
+// partial sums meet once in LDS, and waves 0 .. FM - 1 run the epilogue.  Same MFMA, fp32
+// accumulation and epilogue as above; the order of the K summation differs.
+constexpr int SKINNY_WAVES = 8;
+
+template <int FM>
+__global__ void __launch_bounds__(SKINNY_WAVES * 64)
+dense_bf16_skinny_kernel(DenseArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[SKINNY_WAVES][FM][64][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  int64_t nrow = n0 + fr;
+  if (nrow > a.N - 1) nrow = a.N - 1;
+  const bf16 *wp = a.w + nrow * a.K + fq * 8;
+  const bf16 *xp[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int64_t m = i * 16 + fr;
+    if (m > a.M - 1) m = a.M - 1;
+    xp[i] = a.x + m * a.ldx + fq * 8;
+  }
+  f32x4 acc[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // k-steps of 32, dealt out round robin: neighbouring waves read the two halves of a 128-byte line
+  const int nks = (int)(a.K >> 5);
+  const int cnt = nks > wave ? (nks - wave + SKINNY_WAVES - 1) / SKINNY_WAVES : 0;
+  int t = 0;
+  for (; t + 4 <= cnt; t += 4) {   // the loads of four k-steps in flight before the first MFMA
+    bf16x8 wf[4], xf[4][FM];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t off = (int64_t)(wave + SKINNY_WAVES * (t + u)) * 32;
+      wf[u] = *reinterpret_cast<const bf16x8 *>(wp + off);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) xf[u][i] = *reinterpret_cast<const bf16x8 *>(xp[i] + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][i], acc[i], 0, 0, 0);
+  }
+  for (; t < cnt; ++t) {
+    const int64_t off = (int64_t)(wave + SKINNY_WAVES * t) * 32;
+    const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wp + off);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8 *>(xp[i] + off);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) *reinterpret_cast<f32x4 *>(&red[wave][i][lane][0]) = acc[i];
+  __syncthreads();
+  if (wave >= FM) return;
+  const int i = wave;                       // this wave finishes rows 16 i .. 16 i + 15
+  f32x4 sum = *reinterpret_cast<const f32x4 *>(&red[0][i][lane][0]);
+#pragma unroll
+  for (int w = 1; w < SKINNY_WAVES; ++w) {
+    const f32x4 p = *reinterpret_cast<const f32x4 *>(&red[w][i][lane][0]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum[e] += p[e];
+  }
+  // lane holds out[m][n .. n + 3]
+  const int64_t n = n0 + fq * 4, m = i * 16 + fr;
+  if (n >= a.N || m >= a.M) return;
+  float v[4];
+  if (a.bias) {
+    const bf16x4 b4 = *reinterpret_cast<const bf16x4 *>(a.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum[e] += (float)b4[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = apply_act<false>(sum[e], a.act);
+  if (a.other) {
+    const bf16x4 o4 = *reinterpret_cast<const bf16x4 *>(a.other + m * a.ldother + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = a.combine == GNLP_COMBINE_MUL ? v[e] * (float)o4[e] : v[e] + (float)o4[e];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+  *reinterpret_cast<bf16x4 *>(a.out + m * a.ldo + n) = o;
+}
+
+static void launch_skinny(const DenseArgs &a, hipStream_t s) {
+  const dim3 grid((unsigned)((a.N + 15) / 16)), block(SKINNY_WAVES * 64);
+  if (a.M <= 16) dense_bf16_skinny_kernel<1><<<grid, block, 0, s>>>(a);
+  else if (a.M <= 32) dense_bf16_skinny_kernel<2><<<grid, block, 0, s>>>(a);
+  else dense_bf16_skinny_kernel<4><<<grid, block, 0, s>>>(a);
+}
+
 bool mfma_bf16_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
                                int64_t ldother, const void *x, const void *w, const void *out,
                                const void *other) {
@@ -246,6 +347,8 @@ void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void 
     launch_mfma_bf16_dense_w4(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
   else if (big && mfma_bf16_dense_pp_supported(N, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_pp(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
+  else if (M <= 64 && N <= 16 * 65535LL && knobs().gemm_tile == 0)
+    launch_skinny(a, s);     // a few rows: decoding steps
   else
     launch_cfg<128, 128, 2, 2>(a, s);
 }

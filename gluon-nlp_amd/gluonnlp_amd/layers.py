@@ -219,6 +219,31 @@ def _norm_kind(layer):
 # ------------------------------------------------------------------------------------------
 # Dense  (mxnet nn.Dense(flatten=False))
 # ------------------------------------------------------------------------------------------
+def memory_kv(prev_state, mem, k_dense, v_dense):
+    """-> (k_dense(mem), v_dense(mem), kept) for a decoder layer's memory attention during
+    incremental decoding.  The reference projects the whole memory again at every target position
+    (models/transformer.py:716-724, models/t5.py:462-470): B * L_mem rows through two GEMMs per
+    layer and step for a result that does not change.  Here the pair travels with the decoding
+    state: the caller attaches ``kept`` to the key cache it returns (attribute
+    ``_gnlp_memory_kv``), and the next step takes the pair from the cache it is handed
+    (``prev_state``) when the very same memory tensor object comes in again with its version
+    counter, and the four parameters with their storage and version counters, unchanged.  The
+    first step, states that went through a reordering (beam search), autograd, non-torch callers
+    (a fresh DLPack view per call) and every mismatch recompute."""
+    m = T.as_tensor(mem)
+    params = [p for p in (k_dense.weight, k_dense.bias, v_dense.weight, v_dense.bias)
+              if p is not None]
+    key = None
+    if m is mem and not wants_grad(m, *params):
+        key = (m._version, m.data_ptr(), tuple(m.shape), tuple(m.stride()), m.dtype) + \
+            tuple((p.data_ptr(), p._version) for p in params)
+        hit = getattr(prev_state, '_gnlp_memory_kv', None)
+        if hit is not None and hit[0] is m and hit[1] == key:
+            return hit[2], hit[3], hit
+    k, v = T.as_tensor(k_dense(m)), T.as_tensor(v_dense(m))
+    return k, v, ((m, key, k, v) if key is not None else None)
+
+
 class Dense(nn.Module):
     """y = act(x W^T + b) with W of shape (units, in_units); optional fused ``other`` operand
     (residual add or gate multiply)."""

@@ -12,7 +12,7 @@ from .. import _lib
 from .. import _tensor as T
 from ..attention_cell import (MultiHeadAttentionCell, RelAttentionScoreCell, gen_mem_attn_mask,
                               gen_rel_position, gen_self_attn_mask, mask_predicate)
-from ..layers import Dense, Embedding, PositionwiseFFN, RMSNorm, ffn_params_struct
+from ..layers import Dense, Embedding, PositionwiseFFN, RMSNorm, ffn_params_struct, memory_kv
 
 __all__ = ['T5Block', 'T5Encoder', 'T5Decoder', 'T5Model']
 
@@ -92,15 +92,30 @@ class T5Block(nn.Module):
     def packed_qkv(self):
         """[q; k; v] weights packed row-wise into one (3 * inner, d_model) buffer, so that the
         block's three projections are ONE GEMM of N = 3 * inner (the reference keeps three Dense
-        layers, models/t5.py:296-318, and so do the parameter names here).  The copy is rebuilt
-        whenever one of the three parameters was replaced or edited in place."""
-        ws = [self.self_attn_q.weight.data, self.self_attn_k.weight.data,
-              self.self_attn_v.weight.data]
-        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
-        if getattr(self, '_qkv_key', None) != key:
-            self._qkv_packed = torch.cat(ws, dim=0).contiguous()
-            self._qkv_key = key
-        return self._qkv_packed
+        layers, models/t5.py:296-318, and so do the parameter names here).  The buffer is not a
+        copy that could go stale: the three parameters are re-seated as row slices OF it, so
+        every in-place edit (load_state_dict, ``p.data.copy_``, an optimizer step -- version
+        counters do not see edits through ``.data``) lands in the packed storage itself; a
+        parameter whose storage was replaced (``.to()``, ``.cuda()``, ``p.data = ...``) no longer
+        points into the buffer, which is then rebuilt."""
+        ps = [self.self_attn_q.weight, self.self_attn_k.weight, self.self_attn_v.weight]
+        buf = getattr(self, '_qkv_packed', None)
+        if buf is not None:
+            row_bytes = buf.shape[1] * buf.element_size()
+            at, ok = buf.data_ptr(), True
+            for p in ps:
+                ok = ok and (p.data_ptr() == at and p.dtype == buf.dtype and p.device == buf.device
+                             and p.is_contiguous() and p.shape[1] == buf.shape[1])
+                at += p.shape[0] * row_bytes
+            if ok:
+                return buf
+        buf = torch.cat([p.data for p in ps], dim=0).contiguous()
+        at = 0
+        for p in ps:
+            p.data = buf[at:at + p.shape[0]]
+            at += p.shape[0]
+        object.__setattr__(self, '_qkv_packed', buf)
+        return buf
 
     def params_struct(self):
         p = _lib.T5BlockParams()
@@ -142,11 +157,17 @@ class T5Block(nn.Module):
         x = T.as_tensor(x)
         return x.reshape(x.shape[0], x.shape[1], self._num_heads, -1)
 
-    def _cross_and_ffn(self, hidden_states, mem_states, mem_attn_mask):
+    def _cross_and_ffn(self, hidden_states, mem_states, mem_attn_mask, states=None):
         out = self.cross_attn_layer_norm(hidden_states)
         q = self.transpose_for_scores(self.cross_attn_q(out))
-        k = self.transpose_for_scores(self.cross_attn_k(mem_states))
-        v = self.transpose_for_scores(self.cross_attn_v(mem_states))
+        if states is not None:   # incremental decoding: (previous, new) key cache; the memory's
+            # projections travel with the decoding state instead of being recomputed per step
+            k, v, kept = memory_kv(states[0], mem_states, self.cross_attn_k, self.cross_attn_v)
+            if kept is not None:
+                states[1]._gnlp_memory_kv = kept
+        else:
+            k, v = self.cross_attn_k(mem_states), self.cross_attn_v(mem_states)
+        k, v = self.transpose_for_scores(k), self.transpose_for_scores(v)
         out, _ = self.cross_attn(q, k, v, mem_attn_mask, _need_scores=False, _need_weights=False)
         hidden_states = self.cross_attn_proj(out, other=hidden_states, combine='add')
         return self.ffn(hidden_states)
@@ -168,7 +189,8 @@ class T5Block(nn.Module):
         out, _ = self.self_attn(q, self_key, self_value, None, step_position_embeddings,
                                 _need_scores=False, _need_weights=False)
         x = self.self_attn_proj(out, other=x, combine='add')
-        x = self._cross_and_ffn(x, mem_states, step_mem_attn_mask)
+        x = self._cross_and_ffn(x, mem_states, step_mem_attn_mask,
+                                states=(past_key_value[0], self_key))
         return T.like_caller(T.as_tensor(x), step_hidden_states), (self_key, self_value)
 
     def forward(self, hidden_states, self_attn_mask, position_embeddings, mem_states=None,

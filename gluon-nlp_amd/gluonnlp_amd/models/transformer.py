@@ -12,7 +12,7 @@ from .. import _lib
 from .. import _tensor as T
 from ..attention_cell import (MultiHeadAttentionCell, gen_mem_attn_mask, gen_self_attn_mask,
                               mask_predicate)
-from ..layers import Dense, LayerNorm, PositionwiseFFN, ffn_params_struct
+from ..layers import Dense, LayerNorm, PositionwiseFFN, ffn_params_struct, memory_kv
 
 __all__ = ['TransformerEncoderLayer', 'TransformerEncoder', 'run_encoder_stack',
            'TransformerDecoderLayer', 'TransformerDecoder']
@@ -334,10 +334,11 @@ class TransformerDecoderLayer(nn.Module):
         x = T.as_tensor(out)
         if self._pre_norm:
             x = self.ln_inter(x)
-        m = T.as_tensor(mem)
+        mem_k, mem_v, kept = memory_kv(prev_key, mem, self.attn_inter_k, self.attn_inter_v)
+        if kept is not None:
+            new_key._gnlp_memory_kv = kept       # the projections travel with the decoding state
         out, _ = self.inter_attention(self._heads(T.as_tensor(self.attn_inter_q(x))),
-                                      self._heads(T.as_tensor(self.attn_inter_k(m))),
-                                      self._heads(T.as_tensor(self.attn_inter_v(m))),
+                                      self._heads(mem_k), self._heads(mem_v),
                                       mem_attn_mask, _need_scores=False, _need_weights=False)
         out = self.proj_inter(out, other=x)
         if not self._pre_norm:

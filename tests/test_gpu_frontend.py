@@ -408,3 +408,121 @@ def test_bert_model_from_reference_layout_parameter_file(nlp, suffix):
             assert rel_err(seq_n[b, :vl[b]], want_seq[b, :vl[b]]) < t, (dn, b)
             assert (seq_n[b, vl[b]:] == 0).all()
         assert rel_err(to_np(pooled), want_pooled) < t
+
+
+@pytest.mark.parametrize('kind', ['transformer', 't5'])
+def test_incremental_decode_keeps_memory_projections(nlp, kind):
+    """During incremental decoding the memory's key / value projections are computed once and
+    travel with the decoding state instead of being recomputed per step (the reference recomputes
+    them, models/transformer.py:716-724, models/t5.py:462-470: same values).  The kept pair is
+    used only for the very same memory tensor object with unchanged contents and parameters, from
+    the state the previous step returned: an in-place edit of the memory, an edited weight,
+    another tensor or a reordered state recompute -- and every step agrees bit for bit with
+    layers that never keep anything."""
+    from gluonnlp_amd import layers as L
+    from gluonnlp_amd._tensor import as_tensor
+    from gluonnlp_amd.models import T5Decoder, TransformerDecoder
+    import gluonnlp_amd.models.t5 as m5
+    import gluonnlp_amd.models.transformer as mt
+    torch.manual_seed(3)
+    B, LM, U = 2, 9, 64
+    if kind == 'transformer':
+        m = TransformerDecoder(num_layers=2, units=U, mem_units=U, hidden_size=128, num_heads=2,
+                               dtype='bfloat16', layout='NT').cuda()
+        kd = m.layers[0].attn_inter_k
+        init = lambda: m.init_states(B, 'cuda', 'bfloat16')
+        step = lambda i, x, st, mem, mvl: m.incremental_decode(x[:, 0], st, mem, mvl)
+    else:
+        m = T5Decoder(d_model=U, d_kv=32, d_ff=128, num_layers=2, num_heads=2, dtype='bfloat16',
+                      layout='NT').cuda()
+        kd = m.layers[0].cross_attn_k
+        init = lambda: m._init_key_values(B, 'cuda', 'bfloat16')
+        step = lambda i, x, st, mem, mvl: m.incremental_decode(
+            x, torch.full((B,), i, dtype=torch.int32, device='cuda'), st, mem, mvl)
+    for p in m.parameters():
+        p.data.normal_(0, 0.1)
+    mem = torch.randn(B, LM, U, device='cuda').to(torch.bfloat16)
+    mvl = torch.tensor([LM, 4], device='cuda')
+    xs = [torch.randn(B, 1, U, device='cuda').to(torch.bfloat16) for _ in range(6)]
+    calls = []
+    hook = kd.register_forward_hook(lambda *a: calls.append(1))
+    real = L.memory_kv
+    fresh = lambda prev, mem_, k, v: (as_tensor(k(mem_)), as_tensor(v(mem_)), None)
+
+    def decode(keep, edits):
+        """six steps; edits: step index -> callable run before that step (may return new states)"""
+        mt.memory_kv = m5.memory_kv = real if keep else fresh
+        try:
+            st, outs, counts = init(), [], []
+            for i, x in enumerate(xs):
+                if i in edits:
+                    st = edits[i](st) or st
+                o, st = step(i, x, st, mem, mvl)
+                outs.append(o.clone())
+                counts.append(len(calls))
+            return outs, counts
+        finally:
+            mt.memory_kv = m5.memory_kv = real
+
+    def edit_mem(st):
+        mem[:, 0] += 1.0                     # in place: same object, new version
+
+    def edit_weight(st):
+        with torch.no_grad():
+            kd.weight.mul_(0.5)
+
+    def reorder(st):                         # what a beam search does to the states
+        perm = torch.tensor([1, 0], device='cuda')
+        return [tuple(t.index_select(0, perm) for t in pair) for pair in st]
+    edits = {2: edit_mem, 3: edit_weight, 5: reorder}
+    try:
+        snap = {k: v.clone() for k, v in m.state_dict().items()}
+        mem0 = mem.clone()
+        calls.clear()
+        kept, counts = decode(True, edits)
+        # computed at steps 0 (first), 2 (memory edited), 3 (weight edited), 5 (reordered state)
+        assert [b - a for a, b in zip([0] + counts, counts)] == [1, 0, 1, 1, 0, 1]
+        m.load_state_dict(snap)
+        mem.copy_(mem0)
+        calls.clear()
+        ref_outs, counts = decode(False, edits)
+        assert counts[-1] == 6
+        for a, b in zip(kept, ref_outs):
+            assert torch.equal(a, b)
+    finally:
+        hook.remove()
+
+
+def test_t5_packed_qkv_follows_parameter_edits(nlp):
+    """The encoder blocks' packed [q; k; v] weight buffer is the parameters' own storage, not a
+    copy: whatever way the parameters are edited after a first forward (load_state_dict,
+    p.data.copy_, in-place arithmetic, .to()), the next forward uses the new values."""
+    from gluonnlp_amd.models import T5Encoder
+    torch.manual_seed(5)
+    mk = lambda: T5Encoder(64, 32, 128, num_layers=2, num_heads=2, activation='relu',
+                           dtype='bfloat16', layout='NT').cuda()
+    a, b = mk(), mk()
+    for mod in (a, b):
+        for p in mod.parameters():
+            p.data.normal_(0, 0.1)
+    x = torch.randn(2, 10, 64, device='cuda').to(torch.bfloat16)
+    vl = torch.tensor([10, 6], device='cuda')
+    ya0, yb0 = a(x, vl).clone(), b(x, vl).clone()          # both have packed their weights now
+    assert not torch.equal(ya0, yb0)
+    q = a.layers[0].self_attn_q.weight
+    assert q.data_ptr() == a.layers[0].packed_qkv().data_ptr()
+    a.load_state_dict(b.state_dict())                      # param.copy_ under no_grad
+    assert torch.equal(a(x, vl), yb0)
+    for pa in a.parameters():
+        pa.data.mul_(0.5)                                  # invisible to version counters
+    for pb in b.parameters():
+        pb.data.mul_(0.5)
+    yb1 = b(x, vl).clone()
+    assert torch.equal(a(x, vl), yb1) and not torch.equal(yb1, yb0)
+    a.layers[0].self_attn_k.weight.data = b.layers[1].self_attn_k.weight.data.clone()   # re-seated
+    b.layers[0].self_attn_k.weight.data.copy_(b.layers[1].self_attn_k.weight.data)
+    assert torch.equal(a(x, vl), b(x, vl))
+    sd = {k: v.clone() for k, v in a.state_dict().items()}   # round trip through a state dict
+    c = mk()
+    c.load_state_dict(sd)
+    assert torch.equal(c(x, vl), a(x, vl))

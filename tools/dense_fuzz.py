@@ -16,7 +16,11 @@ bad = 0
 for it in range(ncase):
     dtype = torch.bfloat16 if rng.random() < 0.7 else torch.float32
     big = rng.random() < 0.5
-    if big:
+    if rng.random() < 0.3:      # a few rows (decoding steps): the skinny kernel's shapes and edges
+        M = int(rng.integers(1, 70))
+        N = 4 * int(rng.integers(1, 800))
+        K = 64 * int(rng.integers(1, 50))
+    elif big:
         M = 256 * int(rng.integers(1, 20))
         N = int(rng.choice([192, 256, 384, 512, 768, 1024, 2304, 3072]))
         K = 64 * int(rng.integers(1, 40))
