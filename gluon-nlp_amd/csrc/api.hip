@@ -45,6 +45,7 @@ void reload_knobs() {
   k.norm_nt = env_on("GNLP_NORM_NT");
   k.pack_ragged = env_on("GNLP_PACK_RAGGED");
   k.attn_bwd_bf16 = env_on("GNLP_ATTN_BWD_BF16");
+  k.skinny_max_m = env_int("GNLP_SKINNY_MAX_M", 384, 0, 1 << 20);
   const char *mv = getenv("GNLP_NORM_MAXV");
   k.norm_full = mv && mv[0] == 'f';
   g_knobs = k;

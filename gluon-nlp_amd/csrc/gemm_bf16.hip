@@ -172,7 +172,7 @@ dense_bf16_kernel(DenseArgs a) {
   }
 }
 
-// ---- a few rows (M <= 64: one decoding step of a batch) ----
+// ---- a few rows (one decoding step of a batch: M = batch size) ----
 // The tiled kernel above gives such a call N / 128 workgroups, each walking all of K through
 // barriers two 64-wide tiles at a time: 6 workgroups and 19 us for N = K = 768 on a 256-CU chip,
 // for 1.2 MB of weights.  Here a workgroup owns 16 output columns for all rows and its 8 waves
@@ -190,13 +190,14 @@ dense_bf16_skinny_kernel(DenseArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int64_t n0 = (int64_t)blockIdx.x * 16;
+  const int64_t mb = (int64_t)blockIdx.y * (16 * FM);   // first row of this workgroup
   int64_t nrow = n0 + fr;
   if (nrow > a.N - 1) nrow = a.N - 1;
   const bf16 *wp = a.w + nrow * a.K + fq * 8;
   const bf16 *xp[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    int64_t m = i * 16 + fr;
+    int64_t m = mb + i * 16 + fr;
     if (m > a.M - 1) m = a.M - 1;
     xp[i] = a.x + m * a.ldx + fq * 8;
   }
@@ -206,29 +207,26 @@ dense_bf16_skinny_kernel(DenseArgs a) {
   // k-steps of 32, dealt out round robin: neighbouring waves read the two halves of a 128-byte line
   const int nks = (int)(a.K >> 5);
   const int cnt = nks > wave ? (nks - wave + SKINNY_WAVES - 1) / SKINNY_WAVES : 0;
-  int t = 0;
-  for (; t + 4 <= cnt; t += 4) {   // the loads of four k-steps in flight before the first MFMA
+  // the loads of up to four k-steps are in flight before the first MFMA (the guards are uniform
+  // per wave; K = 768 leaves a wave three k-steps: without them it would run them one by one)
+  for (int t = 0; t < cnt; t += 4) {
     bf16x8 wf[4], xf[4][FM];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int64_t off = (int64_t)(wave + SKINNY_WAVES * (t + u)) * 32;
-      wf[u] = *reinterpret_cast<const bf16x8 *>(wp + off);
+      if (t + u < cnt) {
+        const int64_t off = (int64_t)(wave + SKINNY_WAVES * (t + u)) * 32;
+        wf[u] = *reinterpret_cast<const bf16x8 *>(wp + off);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) xf[u][i] = *reinterpret_cast<const bf16x8 *>(xp[i] + off);
+        for (int i = 0; i < FM; ++i) xf[u][i] = *reinterpret_cast<const bf16x8 *>(xp[i] + off);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u) {
+      if (t + u < cnt) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][i], acc[i], 0, 0, 0);
-  }
-  for (; t < cnt; ++t) {
-    const int64_t off = (int64_t)(wave + SKINNY_WAVES * t) * 32;
-    const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wp + off);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const bf16x8 xf = *reinterpret_cast<const bf16x8 *>(xp[i] + off);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i], 0, 0, 0);
+        for (int i = 0; i < FM; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][i], acc[i], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -244,7 +242,7 @@ dense_bf16_skinny_kernel(DenseArgs a) {
     for (int e = 0; e < 4; ++e) sum[e] += p[e];
   }
   // lane holds out[m][n .. n + 3]
-  const int64_t n = n0 + fq * 4, m = i * 16 + fr;
+  const int64_t n = n0 + fq * 4, m = mb + i * 16 + fr;
   if (n >= a.N || m >= a.M) return;
   float v[4];
   if (a.bias) {
@@ -267,10 +265,12 @@ dense_bf16_skinny_kernel(DenseArgs a) {
 }
 
 static void launch_skinny(const DenseArgs &a, hipStream_t s) {
-  const dim3 grid((unsigned)((a.N + 15) / 16)), block(SKINNY_WAVES * 64);
-  if (a.M <= 16) dense_bf16_skinny_kernel<1><<<grid, block, 0, s>>>(a);
-  else if (a.M <= 32) dense_bf16_skinny_kernel<2><<<grid, block, 0, s>>>(a);
-  else dense_bf16_skinny_kernel<4><<<grid, block, 0, s>>>(a);
+  const dim3 block(SKINNY_WAVES * 64);
+  const unsigned gx = (unsigned)((a.N + 15) / 16);
+  if (a.M <= 16) dense_bf16_skinny_kernel<1><<<dim3(gx, 1), block, 0, s>>>(a);
+  else if (a.M <= 32) dense_bf16_skinny_kernel<2><<<dim3(gx, 1), block, 0, s>>>(a);
+  else   // 64 rows per workgroup; more rows: more workgroups along y (the weights come from L2)
+    dense_bf16_skinny_kernel<4><<<dim3(gx, (unsigned)((a.M + 63) / 64)), block, 0, s>>>(a);
 }
 
 bool mfma_bf16_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
@@ -347,7 +347,7 @@ void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void 
     launch_mfma_bf16_dense_w4(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
   else if (big && mfma_bf16_dense_pp_supported(N, ldo, ldother, out, bias, other))
     launch_mfma_bf16_dense_pp(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s);
-  else if (M <= 64 && N <= 16 * 65535LL && knobs().gemm_tile == 0)
+  else if (M <= knobs().skinny_max_m && M <= 64 * 65535LL && knobs().gemm_tile == 0)
     launch_skinny(a, s);     // a few rows: decoding steps
   else
     launch_cfg<128, 128, 2, 2>(a, s);

@@ -37,6 +37,8 @@ struct Knobs {
   bool norm_full;   // GNLP_NORM_MAXV=f: always the full-width register image
   bool pack_ragged; // GNLP_PACK_RAGGED=0: the stack drivers never pack a ragged batch
   bool attn_bwd_bf16; // GNLP_ATTN_BWD_BF16=0: attention backward on the fp32 matrix cores for bf16 too
+  int skinny_max_m; // GNLP_SKINNY_MAX_M: bf16 Dense calls with at most this many rows take the
+                    // K-split kernel (gemm_bf16.hip); 0 = never
 };
 const Knobs &knobs();
 void reload_knobs();

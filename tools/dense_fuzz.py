@@ -17,7 +17,7 @@ for it in range(ncase):
     dtype = torch.bfloat16 if rng.random() < 0.7 else torch.float32
     big = rng.random() < 0.5
     if rng.random() < 0.3:      # a few rows (decoding steps): the skinny kernel's shapes and edges
-        M = int(rng.integers(1, 70))
+        M = int(rng.integers(1, 400))
         N = 4 * int(rng.integers(1, 800))
         K = 64 * int(rng.integers(1, 50))
     elif big:
