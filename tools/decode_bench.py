@@ -20,6 +20,7 @@ x = torch.randn(B, 1, 768, device='cuda').to(torch.bfloat16)
 kept = m5.memory_kv
 
 
+@torch.no_grad()
 def run():
     past = m._init_key_values(B, 'cuda', 'bfloat16')
     for i in range(STEPS):
