@@ -350,9 +350,11 @@ class T5Decoder(nn.Module):
         the step's relative positions from the length of the cached keys instead (:863-870)."""
         past = T.as_tensor(past_key_values[0][0])
         L = past.shape[self._time_axis] + 1
-        # last row of the (L, L) bias = relative positions (mem_j - (L - 1)) of the new query
-        step_position_embeddings = self.relative_position_encoder.self_attn_bias(L)[
-            :, -1:, :].contiguous()
+        # last row of the (L, L) bias = relative positions (mem_j - (L - 1)) of the new query =
+        # the first L entries of the bias' Toeplitz table (bias[h, i, j] = table[h, L - 1 + j - i]):
+        # O(L) per step where the (H, L, L) tensor is O(L^2)
+        step_position_embeddings = self.relative_position_encoder.self_attn_bias_table(L)[
+            :, :L].unsqueeze(1).contiguous()
         step_mem_attn_mask = gen_mem_attn_mask(mem_states, mem_valid_length, step_hidden_states,
                                                dtype=self._dtype, layout=self.layout)
         present_key_values = []
