@@ -330,6 +330,72 @@ def test_dense_persistent(nlp, M, N, K, monkeypatch):
         reload_knobs()
 
 
+@pytest.mark.parametrize('M,N,K', [
+    (1, 768, 768),        # a single row (one sequence decoding): FM = 1
+    (16, 3072, 768),      # one full fragment of rows
+    (17, 772, 3072),      # FM = 2, ragged rows, N not a multiple of 16, long K (12 k-steps a wave)
+    (33, 64, 64),         # FM = 4 in one group, K = 64: six of the eight waves get no k-step
+    (64, 2304, 768),      # 64-row group
+    (65, 768, 1024),      # two row groups, the second with one live row
+    (128, 768, 768),      # 32-row groups (fewer than 128 workgroups of 64 rows)
+    (384, 3072, 768),     # the last row count the kernel takes by default
+])
+def test_dense_few_rows(nlp, M, N, K, monkeypatch):
+    """The K-split bf16 kernel for few rows (decoding steps, small-batch inference;
+    csrc/gemm_bf16.hip dense_bf16_skinny_kernel) against the oracle on every epilogue, and against
+    the tiled kernel on the same buffers (same products, another summation order: fp32 rounding
+    of the accumulator apart); a strided input (the pooler's CLS rows) through the C ABI."""
+    import ctypes
+    from gluonnlp_amd import _lib
+    from gluonnlp_amd.layers import Dense
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(M * 7 + N + K)
+    x = rng.standard_normal((M, K))
+    w = rng.standard_normal((N, K)) * 0.1
+    b = rng.standard_normal(N)
+    o = rng.standard_normal((M, N))
+    d = Dense(N, K, dtype='bfloat16').cuda()
+    d.weight.data, d.bias.data = to_dev(w, dtype), to_dev(b, dtype)
+    nb = Dense(N, K, use_bias=False, dtype='bfloat16').cuda()
+    nb.weight.data = to_dev(w, dtype)
+    xd, od = to_dev(x, dtype), to_dev(o, dtype)
+    xo, wo, bo, oo = prep(x, dtype), prep(w, dtype), prep(b, dtype), prep(o, dtype)
+    base = ref.dense(xo, wo, bo)
+    t = tol(dtype)
+
+    def variants():
+        return [d(xd), d(xd, act='gelu'), d(xd, act='relu'), d(xd, act='gelu(tanh)'),
+                d(xd, other=od), d(xd, other=od, combine='mul', act='gelu(tanh)'), nb(xd),
+                nb(xd, other=od)]
+    want = [base, ref.activation(base, 'gelu'), ref.activation(base, 'relu'),
+            ref.activation(base, 'gelu(tanh)'), base + oo, ref.activation(base, 'gelu(tanh)') * oo,
+            ref.dense(xo, wo), ref.dense(xo, wo) + oo]
+    got = variants()
+    for g, e in zip(got, want):
+        assert rel_err(to_np(g), e) < t
+    for g, h in zip(got, variants()):
+        assert torch.equal(g, h)
+    reload_knobs = _lib.load().gnlp_reload_knobs
+    try:
+        monkeypatch.setenv('GNLP_SKINNY_MAX_M', '0')          # the tiled kernel
+        reload_knobs()
+        for g, h in zip(got, variants()):
+            assert rel_err(to_np(g), to_np(h)) < 1e-2
+    finally:
+        monkeypatch.delenv('GNLP_SKINNY_MAX_M', raising=False)
+        reload_knobs()
+    # rows 0, 3, 6, ... of a wider buffer (ldx = 3 K), output rows 2 N apart
+    xs = torch.zeros((M, 3 * K), dtype=dtype, device='cuda')
+    xs[:, :K] = xd
+    out = torch.full((M, 2 * N), 7.0, dtype=dtype, device='cuda')
+    rc = _lib.load().gnlp_dense(out.data_ptr(), xs.data_ptr(), d.weight.data_ptr(),
+                                d.bias.data_ptr(), None, _lib.COMBINE_ADD, _lib.ACT['identity'],
+                                _lib.BF16, M, N, K, 3 * K, 2 * N, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :N], got[0]) and (out[:, N:] == 7.0).all()
+
+
 def test_dense_mfma_layout_asymmetric(nlp):
     """A = I against an asymmetric B catches transposed fragment maps (exact integer data)."""
     from gluonnlp_amd.layers import Dense
