@@ -400,37 +400,44 @@ attn_fwd_bf16_d64(FusedAttn a) {
         for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
     }
     bf16x8 pf[4];  // B operand fragments of O^T = V^T P^T, k-step s = 2 kb + t
-    const f32x2 c2 = {c_scale, c_scale};
-    const f32x2 nm2 = {-m_run, -m_run};
-    f32x2 ps2 = {0.0f, 0.0f};
+    // Single-issue v_fma_f32 / v_add_f32 on purpose (the file is built with -fno-slp-vectorize):
+    // a packed f32 instruction does not run beside another wave's MFMAs at all
+    // (tools/coissue_probe2.hip: 112 v_pk_fma_f32 beside 16 MFMAs of the SIMD partner take
+    // 576 + 512 cycles, 112 v_fma_f32 653), and three waves share a SIMD here.
+    float nm = -m_run;
+    float ps0 = 0.0f, ps1 = 0.0f;
     if (tail) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          const f32x2 s2 = {sacc[kb][e], sacc[kb][e + 1]};
-          const f32x2 t2 = s2 * c2 + nm2;
-          f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
-          p2[0] = s2[0] > -1.0e29f ? p2[0] : 0.0f;
-          p2[1] = s2[1] > -1.0e29f ? p2[1] : 0.0f;
-          ps2 += p2;
-          pf[2 * kb + (e >> 3)][e & 7] = (bf16)p2[0];
-          pf[2 * kb + (e >> 3)][(e & 7) + 1] = (bf16)p2[1];
+          const float s0 = sacc[kb][e], s1 = sacc[kb][e + 1];
+          float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0, c_scale, nm));
+          float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1, c_scale, nm));
+          p0 = s0 > -1.0e29f ? p0 : 0.0f;
+          p1 = s1 > -1.0e29f ? p1 : 0.0f;
+          ps0 += p0;
+          ps1 += p1;
+          pf[2 * kb + (e >> 3)][e & 7] = (bf16)p0;
+          pf[2 * kb + (e >> 3)][(e & 7) + 1] = (bf16)p1;
         }
     } else {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          const f32x2 s2 = {sacc[kb][e], sacc[kb][e + 1]};
-          const f32x2 t2 = s2 * c2 + nm2;
-          const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
-          ps2 += p2;
-          pf[2 * kb + (e >> 3)][e & 7] = (bf16)p2[0];
-          pf[2 * kb + (e >> 3)][(e & 7) + 1] = (bf16)p2[1];
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][e], c_scale, nm));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][e + 1], c_scale, nm));
+          ps0 += p0;
+          ps1 += p1;
+          pf[2 * kb + (e >> 3)][e & 7] = (bf16)p0;
+          pf[2 * kb + (e >> 3)][(e & 7) + 1] = (bf16)p1;
+          // (one fragment at a time -- the next one's multiply-adds depend on this opaque copy of
+          // nm: all 32 of them hoisted ahead of the exponentials cost 30 registers and spills)
+          if ((e & 7) == 6) asm volatile("" : "+v"(nm), "+v"(ps0), "+v"(ps1));
         }
     }
-    l_run += ps2[0] + ps2[1];
+    l_run += ps0 + ps1;
 
     // ---- O^T += V^T P^T ----
 #pragma unroll

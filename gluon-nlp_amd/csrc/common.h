@@ -85,42 +85,56 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(r, x);
 }
 
-// erf-GELU for the bf16 epilogues: x * Phi(x) with Phi(x) ~= sigmoid(x (a1 + a3 x^2 + a5 x^4)),
-// minimax-fitted on [-8, 8]: |gelu error| < 2.6e-5 absolute (bf16 resolution near 1 is 3.9e-3).
-// 6 plain VALU ops + v_exp + v_rcp instead of the ~25 of an erf evaluation.
+// erf-GELU for the bf16 epilogues without a transcendental instruction:  x * Phi(x)  with
+//   Phi(x) ~= sat(0.5 + u Q(y)),   u = x / 4,   y = sat(u^2),   sat = the clamp modifier (to [0, 1])
+// Q of degree 6: minimax fit by tools/fit/gelu_poly_fit.py against the bound tests/test_gpu_ops.py
+// asserts; |gelu error| < 1.9e-4 absolute (bf16 resolution near 1 is 3.9e-3).  Beyond |x| = 4 the
+// polynomial sees y = 1 and Q(1) >= 0.5: Phi is exactly 1 / 0, gelu(x) = x for large x and -0 for
+// very negative x.  10 instructions per pair against 11 for round 2's sigmoid form (x^2 (a1 + a3 x^2
+// + a5 x^4) through v_exp + v_rcp); what a drain pays is the instruction COUNT, ~9 cycles each,
+// transcendental or not (same-box A / B) -- hence degree 6, not 7.
+#define GELU_POLY_RC 0.25f
+#define GELU_POLY_DEG 6
+#define GELU_POLY_Q {1.5914379358291626f, -4.130927562713623f, 8.972149848937988f, \
+                     -13.306079864501953f, 12.52656078338623f, -6.672885894775391f, \
+                     1.5197588205337524f}
+
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  // (x / 8)^2 saturated to [0, 1] by the multiply's clamp modifier: the polynomial only ever sees
-  // x^2 <= 64 (beyond, a5 < 0 would turn it over) and no separate clamp instruction is needed;
-  // the power-of-two scalings are exact, so |x| <= 8 gives the bits of the unscaled form
-  const float kL2E = -1.44269504088896340736f;
-  const float a1 = 1.59501575f * kL2E, a3 = 64.0f * 7.40113036e-02f * kL2E,
-              a5 = 4096.0f * -7.03035306e-04f * kL2E;
-  const float xs = x * 0.125f;
-  float y;
-  asm("v_mul_f32_e64 %0, %1, %1 clamp" : "=v"(y) : "v"(xs));
-  float t = fmaf(y, a5, a3);
-  t = fmaf(y, t, a1);
-  const float e = __builtin_amdgcn_exp2f(x * t);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
+  constexpr float q[GELU_POLY_DEG + 1] = GELU_POLY_Q;
+  const float u = x * GELU_POLY_RC;
+  float y, phi;
+  asm("v_mul_f32_e64 %0, %1, %1 clamp" : "=v"(y) : "v"(u));
+  float t = q[GELU_POLY_DEG];
+#pragma unroll
+  for (int k = GELU_POLY_DEG - 1; k >= 0; --k) t = fmaf(t, y, q[k]);
+  asm("v_fma_f32 %0, %1, %2, 0.5 clamp" : "=v"(phi) : "v"(u), "v"(t));
+  return x * phi;
 }
 
-__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {   // two elements, v_pk_* math
-  const float kL2E = -1.44269504088896340736f;
-  const f32x2 a1 = {1.59501575f * kL2E, 1.59501575f * kL2E};
-  const f32x2 a3 = {64.0f * 7.40113036e-02f * kL2E, 64.0f * 7.40113036e-02f * kL2E};
-  const f32x2 a5 = {4096.0f * -7.03035306e-04f * kL2E, 4096.0f * -7.03035306e-04f * kL2E};
-  const f32x2 one = {1.0f, 1.0f};
-  const f32x2 eighth = {0.125f, 0.125f};
-  const f32x2 xs = x * eighth;
-  f32x2 y;
-  asm("v_pk_mul_f32 %0, %1, %1 clamp" : "=v"(y) : "v"(xs));
-  f32x2 t = y * a5 + a3;
-  t = y * t + a1;
-  const f32x2 u = x * t;
-  const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
-  const f32x2 d = one + e;
-  const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  return x * r;
+// N pairs in lockstep (v_pk_* math): the Horner chain of one pair is serial and a drain has one
+// wave per SIMD -- chain by chain the compiler pads every step with an s_nop
+template <int N>
+__device__ __forceinline__ void gelu_erf_fast2_n(f32x2 (&x)[N]) {
+  constexpr float q[GELU_POLY_DEG + 1] = GELU_POLY_Q;
+  const f32x2 rc = {GELU_POLY_RC, GELU_POLY_RC};
+  const f32x2 half = {0.5f, 0.5f};
+  f32x2 u[N], y[N], t[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) u[c] = x[c] * rc;
+#pragma unroll
+  for (int c = 0; c < N; ++c) asm("v_pk_mul_f32 %0, %1, %1 clamp" : "=v"(y[c]) : "v"(u[c]));
+#pragma unroll
+  for (int c = 0; c < N; ++c) t[c] = y[c] * (f32x2){q[GELU_POLY_DEG], q[GELU_POLY_DEG]} +
+                                     (f32x2){q[GELU_POLY_DEG - 1], q[GELU_POLY_DEG - 1]};
+#pragma unroll
+  for (int k = GELU_POLY_DEG - 2; k >= 0; --k)
+#pragma unroll
+    for (int c = 0; c < N; ++c) t[c] = t[c] * y[c] + (f32x2){q[k], q[k]};
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t[c]) : "v"(u[c]), "v"(t[c]), "v"(half));
+#pragma unroll
+  for (int c = 0; c < N; ++c) x[c] = x[c] * t[c];
 }
 
 template <bool EXACT>

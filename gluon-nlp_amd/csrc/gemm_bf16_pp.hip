@@ -247,12 +247,15 @@ dense_bf16_pp_kernel(DensePPArgs a) {
       const f32x4 hi = *reinterpret_cast<const f32x4 *>(rp + (((2 * c8 + 1) ^ (row & 15)) << 4));
       float v[8];
       if (ACT == GNLP_ACT_GELU_ERF) {   // packed-math form: 2 elements per VALU instruction
+        f32x2 g[4];
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-          const f32x2 g0 = gelu_erf_fast2((f32x2){lo[e] + bv[e], lo[e + 1] + bv[e + 1]});
-          const f32x2 g1 = gelu_erf_fast2((f32x2){hi[e] + bv[4 + e], hi[e + 1] + bv[5 + e]});
-          v[e] = g0[0]; v[e + 1] = g0[1]; v[4 + e] = g1[0]; v[5 + e] = g1[1];
+          g[e >> 1] = (f32x2){lo[e] + bv[e], lo[e + 1] + bv[e + 1]};
+          g[2 + (e >> 1)] = (f32x2){hi[e] + bv[4 + e], hi[e + 1] + bv[5 + e]};
         }
+        gelu_erf_fast2_n<4>(g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[2 * c] = g[c][0]; v[2 * c + 1] = g[c][1]; }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

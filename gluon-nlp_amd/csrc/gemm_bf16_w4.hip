@@ -373,19 +373,21 @@ dense_bf16_w4_kernel(DenseW4Args a) {
             // pairs throughout (v_pk_add_f32 / v_cvt_pk_bf16_f32): left to itself the compiler
             // shuffles the identity epilogue through v_perm / v_alignbit (600 instead of 256
             // vector-ALU instructions per tile)
+            f32x2 g[4];   // columns 0 1 | 2 3 | 4 5 | 6 7
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-              f32x2 g0 = (f32x2){lo[q][it][e], lo[q][it][e + 1]} + (f32x2){bv[e], bv[e + 1]};
-              f32x2 g1 = (f32x2){hi[q][it][e], hi[q][it][e + 1]} + (f32x2){bv[4 + e], bv[5 + e]};
-              if (ACT == GNLP_ACT_GELU_ERF) {
-                g0 = gelu_erf_fast2(g0);
-                g1 = gelu_erf_fast2(g1);
-              } else if (ACT != GNLP_ACT_IDENTITY) {
-                g0 = (f32x2){apply_act<false>(g0[0], ACT), apply_act<false>(g0[1], ACT)};
-                g1 = (f32x2){apply_act<false>(g1[0], ACT), apply_act<false>(g1[1], ACT)};
-              }
-              v[e] = g0[0]; v[e + 1] = g0[1]; v[4 + e] = g1[0]; v[5 + e] = g1[1];
+              g[e >> 1] = (f32x2){lo[q][it][e], lo[q][it][e + 1]} + (f32x2){bv[e], bv[e + 1]};
+              g[2 + (e >> 1)] = (f32x2){hi[q][it][e], hi[q][it][e + 1]} + (f32x2){bv[4 + e], bv[5 + e]};
             }
+            if (ACT == GNLP_ACT_GELU_ERF) {
+              gelu_erf_fast2_n<4>(g);
+            } else if (ACT != GNLP_ACT_IDENTITY) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                g[c] = (f32x2){apply_act<false>(g[c][0], ACT), apply_act<false>(g[c][1], ACT)};
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[2 * c] = g[c][0]; v[2 * c + 1] = g[c][1]; }
             if (HAS_OTHER) {
               const bf16x8 o8 = ring[k % 3][q][it];
               if (a.combine == GNLP_COMBINE_MUL) {

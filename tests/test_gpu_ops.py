@@ -411,8 +411,8 @@ def test_dense_mfma_layout_asymmetric(nlp):
 
 @pytest.mark.parametrize('M', [256, 32768])
 def test_dense_gelu_epilogue_wide_range(nlp, M):
-    """The bf16 GELU epilogue (sigmoid-polynomial form, x^2 saturated through the multiply's clamp
-    modifier) over pre-activations in [-30, 30], through the 128x128 kernel (M = 256) and the
+    """The bf16 GELU epilogue (x * sat(0.5 + u Q(u^2)), u = x / 4, u^2 and Phi saturated through the
+    clamp modifier; round 2: a sigmoid of a polynomial) over pre-activations in [-30, 30], through the 128x128 kernel (M = 256) and the
     persistent one (M = 32768): the erf GELU within bf16 resolution everywhere, exactly x for large
     x and (-)0 for very negative x -- nothing turns over where the polynomial would."""
     from gluonnlp_amd.layers import Dense
