@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 
 #include "common.h"
@@ -19,8 +20,13 @@ using namespace gnlp;
 
 namespace gnlp {
 namespace {
-Knobs g_knobs;
-std::atomic<int> g_knobs_ready{0};
+// Two instances and an atomic index: a reload fills the idle instance and flips the index, so a
+// reader on a launch path never sees a half-written struct.  (Two reloads racing each other are
+// serialised by the mutex; gnlp_reload_knobs is still not meant to run beside launches that must
+// agree on a knob between two of their reads.)
+Knobs g_knobs[2];
+std::atomic<int> g_knobs_idx{-1};   // -1: not read yet
+std::mutex g_knobs_mu;
 int env_int(const char *name, int dflt, int lo, int hi) {
   const char *e = getenv(name);
   if (!e || !*e) return dflt;
@@ -35,6 +41,7 @@ bool env_on(const char *name) {   // on unless set to something starting with '0
 }
 }  // namespace
 void reload_knobs() {
+  std::lock_guard<std::mutex> lock(g_knobs_mu);
   Knobs k;
   k.group_m = env_int("GNLP_GROUP_M", 8, 1, 64);
   const int tile = env_int("GNLP_GEMM_TILE", 0, 0, 256);
@@ -48,12 +55,19 @@ void reload_knobs() {
   k.skinny_max_m = env_int("GNLP_SKINNY_MAX_M", 384, 0, 1 << 20);
   const char *mv = getenv("GNLP_NORM_MAXV");
   k.norm_full = mv && mv[0] == 'f';
-  g_knobs = k;
-  g_knobs_ready.store(1, std::memory_order_release);
+  k.ln_fold = env_on("GNLP_LN_FOLD");
+  const int cur = g_knobs_idx.load(std::memory_order_acquire);
+  const int nxt = cur == 0 ? 1 : 0;
+  g_knobs[nxt] = k;
+  g_knobs_idx.store(nxt, std::memory_order_release);
 }
 const Knobs &knobs() {
-  if (!g_knobs_ready.load(std::memory_order_acquire)) reload_knobs();
-  return g_knobs;
+  int i = g_knobs_idx.load(std::memory_order_acquire);
+  if (i < 0) {
+    reload_knobs();
+    i = g_knobs_idx.load(std::memory_order_acquire);
+  }
+  return g_knobs[i];
 }
 }  // namespace gnlp
 
@@ -63,6 +77,7 @@ thread_local std::string g_err;
 thread_local int g_attn_kernel = 0;   // which kernel the last attention dispatch on this thread took
 thread_local const int32_t *g_rows_dev = nullptr;   // see dense_rows_dev() in kernels.h
 thread_local int g_stack_packed = 0;   // whether the last stack call on this thread ran packed
+thread_local int g_stack_folded = 0;   // ... with its LayerNorms folded into the GEMMs
 }  // namespace
 namespace gnlp {
 const int32_t *dense_rows_dev() { return g_rows_dev; }
@@ -147,11 +162,11 @@ DenseProfile g_prof;
 // ---- dense dispatcher --------------------------------------------------------------------------
 int dense_launch(void *out, const void *x, const void *w, const void *bias, const void *other,
                  int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
-                 int64_t ldo, int64_t ldother, hipStream_t s);
+                 int64_t ldo, int64_t ldother, hipStream_t s, const DenseFold *fold);
 
 int dense_impl(void *out, const void *x, const void *w, const void *bias, const void *other,
                int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
-               int64_t ldo, int64_t ldother, hipStream_t s) {
+               int64_t ldo, int64_t ldother, hipStream_t s, const DenseFold *fold = nullptr) {
   int slot = -1;
   if (g_prof.armed.load(std::memory_order_acquire) && M == g_prof.M && N == g_prof.N &&
       K == g_prof.K) {
@@ -160,15 +175,25 @@ int dense_impl(void *out, const void *x, const void *w, const void *bias, const 
   }
   if (slot >= 0) (void)hipEventRecord(g_prof.start[slot], s);
   const int rc = dense_launch(out, x, w, bias, other, combine, act, dtype, M, N, K, ldx, ldo,
-                              ldother, s);
+                              ldother, s, fold);
   if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], s);
   return rc;
 }
 
 int dense_launch(void *out, const void *x, const void *w, const void *bias, const void *other,
                int combine, int act, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
-               int64_t ldo, int64_t ldother, hipStream_t s) {
+               int64_t ldo, int64_t ldother, hipStream_t s, const DenseFold *fold) {
   if (M == 0 || N == 0) return GNLP_OK;
+  if (fold && fold->mode) {   // a LayerNorm folded into this GEMM: the persistent kernel only
+    REQUIRE(dtype == GNLP_BF16 && mfma_dense_act_fused(act) &&
+                mfma_bf16_dense_takes_w4(M, N, K, ldx, ldo, ldother, out, bias, other) &&
+                mfma_bf16_dense_w4_fold_supported(*fold, act, combine, other, N),
+            "folded LayerNorm: unsupported Dense shape (M=%lld N=%lld K=%lld)", (long long)M,
+            (long long)N, (long long)K);
+    launch_mfma_bf16_dense_w4(out, x, w, bias, other, combine, act, M, N, K, ldx, ldo, ldother, s,
+                              fold);
+    return check_launch("gnlp_dense (folded LayerNorm)");
+  }
   const bool bias_al = (!bias || ((uintptr_t)bias % 16 == 0)) && mfma_dense_act_fused(act);
   if (dtype == GNLP_BF16 && bias_al &&
       mfma_bf16_dense_supported(M, N, K, ldx, ldo, ldother, x, w, out, other)) {
@@ -526,6 +551,106 @@ bool stack_can_pack(const gnlp_encoder_cfg *c, int64_t B, int64_t L, const void 
       return false;
   }
   return true;
+}
+
+// Whether a post-norm bf16 stack may run with its LayerNorms folded into the GEMMs around them:
+// every GEMM of a layer on the persistent kernel, rows of at most 2048 units, beta present.
+bool stack_can_fold(const gnlp_encoder_cfg *c, int64_t B, int64_t L, const void *ws,
+                    const gnlp_encoder_layer_params *layers,
+                    const gnlp_encoder_layer_folded *folded, int n_layers) {
+  const int64_t U = c->units, F = c->hidden, M = B * L;
+  if (!folded || c->dtype != GNLP_BF16 || c->pre_norm || M % 256 != 0 || U > 2048) return false;
+  if (!mfma_dense_act_fused(c->act) || !row_stats_supported(U, ws)) return false;
+  for (int i = 0; i < n_layers; ++i) {
+    const gnlp_encoder_layer_params *p = &layers[i];
+    const gnlp_encoder_layer_folded *f = &folded[i];
+    if (p->ffn.gate_w || !p->ln_b || !p->ffn.ln_b) return false;
+    if (!f->ffn1_wf || !f->ffn1_c || !f->ffn1_bf) return false;
+    if (i > 0 && (!f->qkv_wf || !f->qkv_c || !f->qkv_bf)) return false;
+    if (((uintptr_t)f->ffn1_c | (uintptr_t)f->ffn1_bf | (uintptr_t)f->ffn1_wf |
+         (uintptr_t)f->qkv_c | (uintptr_t)f->qkv_bf | (uintptr_t)f->qkv_wf |
+         (uintptr_t)p->ln_g | (uintptr_t)p->ln_b | (uintptr_t)p->ffn.ln_g |
+         (uintptr_t)p->ffn.ln_b) % 16)
+      return false;
+    if (!mfma_bf16_dense_takes_w4(M, 3 * U, U, U, 3 * U, 0, ws, p->qkv_b, nullptr) ||
+        !mfma_bf16_dense_takes_w4(M, U, U, U, U, U, ws, p->proj_b, ws) ||
+        !mfma_bf16_dense_takes_w4(M, F, U, U, F, 0, ws, p->ffn.ffn1_b, nullptr) ||
+        !mfma_bf16_dense_takes_w4(M, U, F, F, U, U, ws, p->ffn.ffn2_b, ws))
+      return false;
+  }
+  return true;
+}
+
+// One post-norm layer of a folded stack (models/transformer.py:259-271, layers.py:640-646, the same
+// arithmetic regrouped).  raw_in == null: x is a real tensor (the stack's input); otherwise the
+// layer's input is LayerNorm(raw_in) with the statistics rs_in and the previous layer's
+// ffn.layer_norm (prev), never materialised.  Leaves the raw sum of ffn_2 in raw_out and, unless
+// `last`, its row statistics in rs_out; the last layer's LayerNorm (+ sequence mask) writes `out`.
+int encoder_layer_folded(void *out, const void *x, const void *raw_in, const float *rs_in,
+                         const gnlp_encoder_layer_params *prev, const gnlp_encoder_layer_params *p,
+                         const gnlp_encoder_layer_folded *f, const gnlp_encoder_cfg *c, int64_t B,
+                         int64_t L, const void *vl, int vl_dtype, int final_seq_mask, bool last,
+                         void *raw_out, float *rs_mid, float *rs_out, void *ws, size_t ws_bytes,
+                         hipStream_t s, const int32_t *cu) {
+  const int64_t U = c->units, H = c->heads, M = B * L, d = U / H, F = c->hidden;
+  const EncWs w = enc_ws(c, B, L, false);
+  REQUIRE(ws && ws_bytes >= w.total, "encoder workspace too small: need %zu bytes, got %zu",
+          w.total, ws_bytes);
+  char *base = (char *)ws;
+  const size_t e = esize(c->dtype);
+  int rc;
+  char *qkv = base + w.qkv;
+  DenseFold fd;
+  if (!raw_in) {
+    rc = dense_impl(qkv, x, p->qkv_w, p->qkv_b, nullptr, 0, GNLP_ACT_IDENTITY, c->dtype, M, 3 * U,
+                    U, U, 3 * U, 0, s);
+  } else {   // attn_qkv(LN(raw_in))
+    fd = DenseFold{1, rs_in, f->qkv_c, f->qkv_bf, nullptr, nullptr};
+    rc = dense_impl(qkv, raw_in, f->qkv_wf, nullptr, nullptr, 0, GNLP_ACT_IDENTITY, c->dtype, M,
+                    3 * U, U, U, 3 * U, 0, s, &fd);
+  }
+  if (rc) return rc;
+  gnlp_attn_desc ad;
+  memset(&ad, 0, sizeof(ad));
+  ad.B = B; ad.H = H; ad.Lq = L; ad.Lm = L; ad.dk = d; ad.dv = d;
+  const int64_t sb = cu ? 0 : (c->time_major ? 1 : L), st = cu ? 1 : (c->time_major ? B : 1);
+  ad.q_stride[0] = ad.k_stride[0] = ad.v_stride[0] = sb * 3 * U;
+  ad.q_stride[1] = ad.k_stride[1] = ad.v_stride[1] = d;
+  ad.q_stride[2] = ad.k_stride[2] = ad.v_stride[2] = st * 3 * U;
+  ad.o_stride[0] = sb * U; ad.o_stride[1] = d; ad.o_stride[2] = st * U;
+  const int64_t mstr[3] = {L * L, L, 1};
+  rc = attn_impl(base + w.ctx, nullptr, nullptr, qkv, qkv + (size_t)U * e, qkv + (size_t)2 * U * e,
+                 &ad, c->dtype, nullptr, mstr, vl, vl_dtype, nullptr, nullptr, sqrtf((float)d),
+                 base + w.attn, w.ffn - w.attn, s, cu);
+  if (rc) return rc;
+  // sum = attention_proj(ctx) + data, data = x or LN(raw_in) rebuilt in the drain
+  if (!raw_in) {
+    rc = dense_impl(base + w.sum, base + w.ctx, p->proj_w, p->proj_b, x, GNLP_COMBINE_ADD,
+                    GNLP_ACT_IDENTITY, c->dtype, M, U, U, U, U, U, s);
+  } else {
+    fd = DenseFold{2, rs_in, nullptr, nullptr, prev->ffn.ln_g, prev->ffn.ln_b};
+    rc = dense_impl(base + w.sum, base + w.ctx, p->proj_w, p->proj_b, raw_in, GNLP_COMBINE_ADD,
+                    GNLP_ACT_IDENTITY, c->dtype, M, U, U, U, U, U, s, &fd);
+  }
+  if (rc) return rc;
+  launch_row_stats(rs_mid, base + w.sum, c->ln_eps, M, U, s);
+  // hidden = act(ffn_1(LN(sum)));  raw_out = ffn_2(hidden) + LN(sum)
+  void *hidden = base + w.ffn;   // (ffn_ws of a post-norm, ungated FFN: hidden first)
+  fd = DenseFold{1, rs_mid, f->ffn1_c, f->ffn1_bf, nullptr, nullptr};
+  rc = dense_impl(hidden, base + w.sum, f->ffn1_wf, nullptr, nullptr, 0, c->act, c->dtype, M, F, U,
+                  U, F, 0, s, &fd);
+  if (rc) return rc;
+  fd = DenseFold{2, rs_mid, nullptr, nullptr, p->ln_g, p->ln_b};
+  rc = dense_impl(raw_out, hidden, p->ffn.ffn2_w, p->ffn.ffn2_b, base + w.sum, GNLP_COMBINE_ADD,
+                  GNLP_ACT_IDENTITY, c->dtype, M, U, F, F, U, U, s, &fd);
+  if (rc) return rc;
+  if (last) {
+    launch_norm(out, raw_out, nullptr, p->ffn.ln_g, p->ffn.ln_b, c->dtype, GNLP_NORM_LAYER,
+                c->ln_eps, M, U, final_seq_mask ? vl : nullptr, vl_dtype, B, L, c->time_major, s);
+  } else {
+    launch_row_stats(rs_out, raw_out, c->ln_eps, M, U, s);
+  }
+  return check_launch("folded encoder layer");
 }
 
 int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
@@ -1034,9 +1159,10 @@ size_t gnlp_encoder_workspace_bytes(const gnlp_encoder_cfg *cfg, int64_t B, int6
   if (!cfg || B < 0 || L < 0 || cfg->heads <= 0) return 0;
   // layer scratch + two ping-pong activations for the stack driver
   // (+ the sequence offsets of a packed ragged batch: B + 2 int32)
+  // (+ two (rows, 2) fp32 row-statistics vectors of a stack run with folded LayerNorms)
   return enc_ws(cfg, B, L, want_weights != 0).total +
          2 * align256((size_t)B * L * cfg->units * esize(cfg->dtype)) +
-         align256((size_t)(B + 2) * sizeof(int32_t));
+         align256((size_t)(B + 2) * sizeof(int32_t)) + 2 * align256((size_t)B * L * 2 * sizeof(float));
 }
 
 int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_layer_params *p,
@@ -1083,11 +1209,67 @@ int gnlp_encoder_layer_forward_noalloc(void *out, const void *x,
                             final_seq_mask, ws, kStaticScratchBytes, S(stream));
 }
 
+static int encoder_stack_impl(void *out, const void *x, const gnlp_encoder_layer_params *layers,
+                              const gnlp_encoder_layer_folded *folded, int n_layers,
+                              const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                              const void *valid_length, int vl_dtype, int final_seq_mask,
+                              void *const *all_encodings, void *workspace, size_t workspace_bytes,
+                              gnlp_stream_t stream);
+
 int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_layer_params *layers,
                                int n_layers, const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
                                const void *valid_length, int vl_dtype, int final_seq_mask,
                                void *const *all_encodings, void *workspace, size_t workspace_bytes,
                                gnlp_stream_t stream) {
+  return encoder_stack_impl(out, x, layers, nullptr, n_layers, cfg, B, L, valid_length, vl_dtype,
+                            final_seq_mask, all_encodings, workspace, workspace_bytes, stream);
+}
+
+int gnlp_encoder_stack_forward_folded(void *out, const void *x,
+                                      const gnlp_encoder_layer_params *layers,
+                                      const gnlp_encoder_layer_folded *folded, int n_layers,
+                                      const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                                      const void *valid_length, int vl_dtype, int final_seq_mask,
+                                      void *workspace, size_t workspace_bytes,
+                                      gnlp_stream_t stream) {
+  REQUIRE(folded != nullptr, "folded parameters are NULL (use gnlp_encoder_stack_forward)");
+  return encoder_stack_impl(out, x, layers, folded, n_layers, cfg, B, L, valid_length, vl_dtype,
+                            final_seq_mask, nullptr, workspace, workspace_bytes, stream);
+}
+
+int gnlp_stack_last_folded(void) { return g_stack_folded; }
+
+int gnlp_fold_norm_dense(void *wf, float *c, float *bf, const void *w, const void *b,
+                         const void *gamma, const void *beta, int dtype, int64_t N, int64_t K,
+                         int64_t n_scaled, float scale, gnlp_stream_t stream) {
+  REQUIRE(dtype == GNLP_BF16, "gnlp_fold_norm_dense: bfloat16 parameters only");
+  REQUIRE(N >= 0 && K >= 0 && K % 8 == 0, "bad shape N=%lld K=%lld (K a multiple of 8)",
+          (long long)N, (long long)K);
+  if (N == 0) return GNLP_OK;
+  REQUIRE(wf && c && bf && w && gamma, "NULL tensors");
+  REQUIRE(((uintptr_t)wf | (uintptr_t)w | (uintptr_t)gamma | (uintptr_t)(beta ? beta : gamma)) % 16 == 0,
+          "gnlp_fold_norm_dense: 16-byte aligned tensors");
+  launch_fold_norm_dense(wf, c, bf, w, b, gamma, beta, N, K, n_scaled, scale, S(stream));
+  return check_launch("gnlp_fold_norm_dense");
+}
+
+int gnlp_row_stats(float *rstats, const void *x, int dtype, float eps, int64_t rows, int64_t C,
+                   gnlp_stream_t stream) {
+  REQUIRE(dtype == GNLP_BF16, "gnlp_row_stats: bfloat16 rows only");
+  REQUIRE(rows >= 0 && C >= 1, "bad shape");
+  if (rows == 0) return GNLP_OK;
+  REQUIRE(rstats && x && row_stats_supported(C, x) && (uintptr_t)rstats % 8 == 0,
+          "gnlp_row_stats: rows of at most 2048 elements, a multiple of 8, 16-byte aligned");
+  launch_row_stats(rstats, x, eps, rows, C, S(stream));
+  return check_launch("gnlp_row_stats");
+}
+
+static int encoder_stack_impl(void *out, const void *x, const gnlp_encoder_layer_params *layers,
+                              const gnlp_encoder_layer_folded *folded, int n_layers,
+                              const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                              const void *valid_length, int vl_dtype, int final_seq_mask,
+                              void *const *all_encodings, void *workspace, size_t workspace_bytes,
+                              gnlp_stream_t stream) {
   int rc = check_encoder_cfg(cfg, B, L);
   if (rc) return rc;
   REQUIRE(layers && n_layers >= 1, "no layers");
@@ -1109,6 +1291,47 @@ int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_laye
   // the same keys).  Needs the persistent GEMM for all four shapes and the fused attention kernel.
   const size_t cu_bytes = align256((size_t)(B + 2) * sizeof(int32_t));
   g_stack_packed = 0;
+  g_stack_folded = 0;
+  // LayerNorms folded into the GEMMs around them: the layers hand each
+  // other RAW pre-norm sums plus two floats of statistics per row; only the last layer's norm runs
+  // as a kernel.  Needs the caller's folded parameters and the persistent GEMM for all four shapes.
+  const size_t rs_bytes = align256((size_t)B * L * 2 * sizeof(float));
+  if (folded && !all_encodings && knobs().ln_fold &&
+      workspace_bytes >= layer_bytes + 2 * act_bytes + cu_bytes + 2 * rs_bytes &&
+      stack_can_fold(cfg, B, L, base, layers, folded, n_layers)) {
+    hipStream_t s = S(stream);
+    float *rs[2] = {(float *)(base + layer_bytes + 2 * act_bytes + cu_bytes),
+                    (float *)(base + layer_bytes + 2 * act_bytes + cu_bytes + rs_bytes)};
+    void *raw = base + enc_ws(cfg, B, L, false).x1;   // (the materialised LN(sum) of the plain path)
+    const bool pack = valid_length && final_seq_mask && knobs().pack_ragged &&
+                      stack_can_pack(cfg, B, L, base, layers, n_layers);
+    const int32_t *cu = nullptr;
+    const void *x0 = x;
+    void *dst = out;
+    if (pack) {
+      int32_t *cuw = (int32_t *)(base + layer_bytes + 2 * act_bytes);
+      launch_seq_offsets(cuw, valid_length, vl_dtype, B, L, s);
+      launch_pack_rows(pp[1], x, cuw, cfg->dtype, B, L, cfg->units, cfg->time_major, s);
+      launch_zero_pad_rows(base + enc_ws(cfg, B, L, false).ctx, cuw, cfg->dtype, B, cfg->units, s);
+      cu = cuw; x0 = pp[1]; dst = pp[0];
+      g_stack_packed = 1;
+    }
+    g_stack_folded = 1;
+    RowsDevScope scope(pack ? cu + B + 1 : nullptr);
+    for (int i = 0; i < n_layers; ++i) {
+      const gnlp_encoder_layer_params *p = &layers[i];
+      REQUIRE(p->qkv_w && p->proj_w && p->ln_g && p->ffn.ffn1_w && p->ffn.ffn2_w && p->ffn.ln_g,
+              "missing weights in layer %d", i);
+      const bool last = i == n_layers - 1;
+      rc = encoder_layer_folded(dst, x0, i ? raw : nullptr, rs[1], i ? &layers[i - 1] : nullptr, p,
+                                &folded[i], cfg, B, L, valid_length, vl_dtype,
+                                pack ? 0 : final_seq_mask, last, raw, rs[0], rs[1], base,
+                                layer_bytes, s, cu);
+      if (rc) return rc;
+    }
+    if (pack) launch_unpack_rows(out, dst, cu, cfg->dtype, B, L, cfg->units, cfg->time_major, s);
+    return check_launch("gnlp_encoder_stack_forward (folded LayerNorm)");
+  }
   if (valid_length && final_seq_mask && !all_encodings && knobs().pack_ragged &&
       workspace_bytes >= layer_bytes + 2 * act_bytes + cu_bytes &&
       stack_can_pack(cfg, B, L, base, layers, n_layers)) {

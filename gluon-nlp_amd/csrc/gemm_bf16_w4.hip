@@ -72,6 +72,10 @@ struct DenseW4Args {
   int K, nk, combine, tiles_m, tiles_n, group_m;
   const int32_t *rows_dev;   // or null: the number of rows to process (a multiple of 256, at most
                              // 256 * tiles_m) is read from device memory (packed ragged batches)
+  // LayerNorm folded into this GEMM (FOLD != 0; kernels.h DenseFold):
+  const float *rstats;       // (rows, 2): r = rsqrt(var + eps) and r * mean of the row's raw sum
+  const float *fold_c, *fold_b;   // FOLD == 1: c[n] = sum_k w'[n, k], b'[n] = beta . w[n, :] + b[n]
+  const bf16 *ln_g, *ln_b;        // FOLD == 2: gamma / beta of the norm `other` goes through
 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -139,11 +143,17 @@ constexpr int w4_find(const int *tab, int n, int t) {
 // B half-panels keep their 16 KiB slots and use 12 KiB of them).  The narrower tile exists for
 // N = 768 / 2304 (BERT-base, T5-base): 384 tiles of 256x256 are two rounds over 256 CUs with half
 // of them idle in the second, 512 tiles of 256x192 are two full rounds of 3/4 the work.
-template <int ACT, bool HAS_OTHER, int NJ>
+// FOLD (LayerNorm folded into the GEMMs around it, bf16 post-norm stacks):
+//   1: x holds the RAW pre-norm sums s and w = bf16(gamma * W); the drain applies the row's
+//      statistics: out = act(r * acc - (r mu) * c[n] + b'[n])  ==  act(LN(s) . W^T + b)
+//   2: `other` holds raw sums s too and the residual is LN(s), rebuilt in the drain in fp32:
+//      out = acc + bias + gamma * (r s - r mu) + beta
+template <int ACT, bool HAS_OTHER, int NJ, int FOLD>
 __global__ void __launch_bounds__(256)
 dense_bf16_w4_kernel(DenseW4Args a) {
 #if __HIP_DEVICE_COMPILE__   // (the buffer-resource builtins exist in the device pass only)
   static_assert(NJ == 8 || NJ == 6, "256- or 192-wide tiles");
+  static_assert(FOLD == 0 || (FOLD == 1 && !HAS_OTHER) || (FOLD == 2 && HAS_OTHER), "fold modes");
   constexpr int NT = 32 * NJ;            // tile width
   constexpr int NQ = NJ / 2;             // 32-row pieces of a B half-panel per wave
   constexpr int HALF = 128 * 128;        // bytes of one half-panel slot (128 rows x 64 bf16)
@@ -294,17 +304,39 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   auto gload = [&](bf16x8 &dst, const bf16 *p) __attribute__((always_inline)) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
   };
+  auto gload_f4 = [&](f32x4 &dst, const float *p) __attribute__((always_inline)) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+  };
+  auto gload_f2 = [&](f32x2 &dst, const float *p) __attribute__((always_inline)) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+  };
+  constexpr bool RING = HAS_OTHER || FOLD != 0;
+  constexpr int NL = (HAS_OTHER ? 4 : 0) + (FOLD != 0 ? 4 : 0);   // operations of one L group
+  constexpr int RD = FOLD == 2 ? 2 : 3;   // ring depth (FOLD 2 holds both rings: registers)
   auto drain = [&](int m0, int n0) __attribute__((always_inline)) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const int c8 = ln & 7, rr8 = ln >> 3, dfr = ln & 15, dfq = ln >> 4;
+    const int c8 = ln & 7, rr8 = ln >> 3;   // (of the slab loads; the groups below derive their own)
     constexpr int WCOLS = NT / 2;
-    bf16x8 ring[3][2][2];
+    bf16x8 ring[RD][2][2];     // residual / gate rows of RD slabs (HAS_OTHER)
+    f32x2 ringst[RD][2][2];    // (r, r mu) of the same rows (FOLD)
     auto slab_n = [&](int hn) -> int64_t {
       const int nj = NJ - hn * 4 < 4 ? NJ - hn * 4 : 4;
       const bool on = c8 * 8 < nj * 16;
       return n0 + wn * WCOLS + hn * 64 + (on ? c8 : 0) * 8;
     };
+    // per-column vectors of the lane's 8 columns in each 64-column group: the oldest loads of the
+    // drain, every later counted wait covers them
+    f32x4 fc[2][2], fb[2][2];   // FOLD == 1: c, b'   (FOLD == 2: bias + beta and gamma sit in LDS)
+    if constexpr (FOLD == 1) {
+#pragma unroll
+      for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          gload_f4(fc[hn][h], a.fold_c + slab_n(hn) + h * 4);
+          gload_f4(fb[hn][h], a.fold_b + slab_n(hn) + h * 4);
+        }
+    }
     auto slab_loads = [&](int k) __attribute__((always_inline)) {   // k = hn * 4 + sp
       const int hn = k >> 2, sp = k & 3;
       const int64_t n = slab_n(hn);
@@ -312,39 +344,73 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-          gload(ring[k % 3][q][it], a.other + (mrow + q * 16 + it * 8) * a.ldother + n);
+        for (int it = 0; it < 2; ++it) {
+          if constexpr (HAS_OTHER)
+            gload(ring[k % RD][q][it], a.other + (mrow + q * 16 + it * 8) * a.ldother + n);
+          if constexpr (FOLD != 0)
+            gload_f2(ringst[k % RD][q][it], a.rstats + (mrow + q * 16 + it * 8) * 2);
+        }
     };
-    if (HAS_OTHER) {
+    // wait for the loads of slab k: the operations younger than L(k) may stay in flight
+    auto slab_wait = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      // RD 3: L0 L1 | L2 [wait L0] S0 | L3 [wait L1] S1 | ... | [wait L6] S6 | [wait L7] S7
+      // RD 2: L0 | L1 [wait L0] S0 | L2 [wait L1] S1 | ... | [wait L7] S7      (S groups: 4 stores)
+      constexpr int FLY = RD == 3 ? (k == 0 ? 2 * NL : k == 1 ? 2 * NL + 4 : k <= 5 ? 2 * NL + 8
+                                                                : k == 6 ? NL + 8 : 8)
+                                  : (k + 1 < 8 ? NL : 0) + (k >= 1 ? 4 : 0);
+      bf16x8(&r)[2][2] = ring[k % RD];
+      f32x2(&t)[2][2] = ringst[k % RD];
+      if constexpr (HAS_OTHER && FOLD != 0)
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(t[0][0]),
+                       "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1])
+                     : "n"(FLY)
+                     : "memory");
+      else if constexpr (HAS_OTHER)
+        asm volatile("s_waitcnt vmcnt(%4)"
+                     : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])
+                     : "n"(FLY)
+                     : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%4)"
+                     : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1])
+                     : "n"(FLY)
+                     : "memory");
+    };
+    if (RING) {
       slab_loads(0);
-      slab_loads(1);
+      if (RD == 3) slab_loads(1);
     }
-#pragma unroll
-    for (int hn = 0; hn < 2; ++hn) {   // 64-column groups of the wave's 128 (96: 64 + 32) columns
+    w4_static_for<2>([&](auto hnc) __attribute__((always_inline)) {   // 64-column groups of the wave's 128 (96: 64 + 32) columns
+      constexpr int hn = decltype(hnc)::value;
+      if constexpr (FOLD == 2) {   // (lane-derived addresses are recomputed per group instead of
+        asm volatile("" : "+v"(ln));   // living across the drain: this instantiation spilled them)
+      }
+      const int c8 = ln & 7, rr8 = ln >> 3, dfr = ln & 15, dfq = ln >> 4;
       const int nj = NJ - hn * 4 < 4 ? NJ - hn * 4 : 4;      // fragments of this group: 4 or 2
       const bool on = c8 * 8 < nj * 16;                      // lanes that own columns of it
       const int64_t n = n0 + wn * WCOLS + hn * 64 + (on ? c8 : 0) * 8;
-      const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(smem + BIAS + n * 2);
       float bv[8];
+      if constexpr (FOLD == 2) {   // fp32 image: bias + beta (gamma: 8 KiB further on)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(smem + BIAS + (n + h * 4) * 4);
 #pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {   // two 16-row slabs per LDS round trip
-        const int k = hn * 4 + sp;
+          for (int e = 0; e < 4; ++e) bv[h * 4 + e] = b4[e];
+        }
+      } else {
+        const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(smem + BIAS + n * 2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
+      }
+      w4_static_for<4>([&](auto spc) __attribute__((always_inline)) {   // two 16-row slabs per LDS round trip
+        constexpr int sp = decltype(spc)::value;
+        constexpr int k = hn * 4 + sp;
         const int64_t mrow = m0 + wm * 128 + sp * 32 + rr8;
-        if (HAS_OTHER) {   // (lanes that are not `on` re-read column group 0: in bounds, unused)
-          if (k + 2 < 8) slab_loads(k + 2);
-          bf16x8(&r)[2][2] = ring[k % 3];
-          // operations younger than L(k) that may stay in flight (see the order above)
-          if (k == 0 || k == 7)
-            asm volatile("s_waitcnt vmcnt(8)"
-                         : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])::"memory");
-          else if (k == 1 || k == 6)
-            asm volatile("s_waitcnt vmcnt(12)"
-                         : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])::"memory");
-          else
-            asm volatile("s_waitcnt vmcnt(16)"
-                         : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])::"memory");
+        if constexpr (RING) {   // (lanes that are not `on` re-read column group 0: in bounds, unused)
+          if constexpr (k + RD - 1 < 8) slab_loads(k + RD - 1);
+          slab_wait(std::integral_constant<int, k>{});
         }
         f32x4 lo[2][2], hi[2][2];
 #pragma unroll
@@ -374,10 +440,25 @@ dense_bf16_w4_kernel(DenseW4Args a) {
             // shuffles the identity epilogue through v_perm / v_alignbit (600 instead of 256
             // vector-ALU instructions per tile)
             f32x2 g[4];   // columns 0 1 | 2 3 | 4 5 | 6 7
+            if constexpr (FOLD == 1) {   // r * acc + (b' - (r mu) c)
+              const f32x2 st = ringst[k % RD][q][it];
+              const f32x2 r2 = {st[0], st[0]}, nm2 = {-st[1], -st[1]};
 #pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-              g[e >> 1] = (f32x2){lo[q][it][e], lo[q][it][e + 1]} + (f32x2){bv[e], bv[e + 1]};
-              g[2 + (e >> 1)] = (f32x2){hi[q][it][e], hi[q][it][e + 1]} + (f32x2){bv[4 + e], bv[5 + e]};
+              for (int e = 0; e < 4; e += 2) {
+                const f32x2 t0 = (f32x2){fc[hn][0][e], fc[hn][0][e + 1]} * nm2 +
+                                 (f32x2){fb[hn][0][e], fb[hn][0][e + 1]};
+                const f32x2 t1 = (f32x2){fc[hn][1][e], fc[hn][1][e + 1]} * nm2 +
+                                 (f32x2){fb[hn][1][e], fb[hn][1][e + 1]};
+                g[e >> 1] = (f32x2){lo[q][it][e], lo[q][it][e + 1]} * r2 + t0;
+                g[2 + (e >> 1)] = (f32x2){hi[q][it][e], hi[q][it][e + 1]} * r2 + t1;
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                g[e >> 1] = (f32x2){lo[q][it][e], lo[q][it][e + 1]} + (f32x2){bv[e], bv[e + 1]};
+                g[2 + (e >> 1)] =
+                    (f32x2){hi[q][it][e], hi[q][it][e + 1]} + (f32x2){bv[4 + e], bv[5 + e]};
+              }
             }
             if (ACT == GNLP_ACT_GELU_ERF) {
               gelu_erf_fast2_n<4>(g);
@@ -388,9 +469,22 @@ dense_bf16_w4_kernel(DenseW4Args a) {
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) { v[2 * c] = g[c][0]; v[2 * c + 1] = g[c][1]; }
-            if (HAS_OTHER) {
-              const bf16x8 o8 = ring[k % 3][q][it];
-              if (a.combine == GNLP_COMBINE_MUL) {
+            if constexpr (HAS_OTHER) {
+              const bf16x8 o8 = ring[k % RD][q][it];
+              if constexpr (FOLD == 2) {   // + gamma * (r s - r mu)   (beta sits in the bias image)
+                // (gamma is re-read from LDS row by row: held in 8 registers this instantiation
+                // spills, and spill traffic would sit in the counted vmcnt queue)
+                const f32x2 st = ringst[k % RD][q][it];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const f32x4 g4 =
+                      *reinterpret_cast<const f32x4 *>(smem + BIAS + 8192 + (n + h * 4) * 4);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    v[h * 4 + e] = __builtin_fmaf(
+                        g4[e], __builtin_fmaf(st[0], (float)o8[h * 4 + e], -st[1]), v[h * 4 + e]);
+                }
+              } else if (a.combine == GNLP_COMBINE_MUL) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= (float)o8[e];
               } else {
@@ -403,10 +497,11 @@ dense_bf16_w4_kernel(DenseW4Args a) {
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
             if (NJ == 8 || on)
               *reinterpret_cast<bf16x8 *>(a.out + (mrow + q * 16 + it * 8) * a.ldo + n) = o;
+            if constexpr (FOLD == 2) W4_SB();   // one row at a time: registers (no spills)
           }
-        if (HAS_OTHER) W4_SB();   // the slab's four stores are issued before the next slab's loads
-      }
-    }
+        if (RING) W4_SB();   // the slab's four stores are issued before the next slab's loads
+      });
+    });
   };
   // ---- producer cursor: the next K-tile to request, running ahead of the MFMAs by two ----
   const int nk = a.nk;
@@ -434,15 +529,36 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 
   // ---- the bias vector goes to LDS once (zeros without a bias) ----
   const bool has_bias = a.bias != nullptr;
-  for (int i = threadIdx.x * 8; i < a.tiles_n * NT; i += 256 * 8) {
-    bf16x8 b8;
-    if (has_bias) {
-      b8 = *reinterpret_cast<const bf16x8 *>(a.bias + i);
-    } else {
+  if constexpr (FOLD == 2) {   // fp32 image (N <= 2048): bias + beta at BIAS, gamma at BIAS + 8 KiB
+    for (int i = threadIdx.x * 8; i < a.tiles_n * NT; i += 256 * 8) {
+      const bf16x8 g8 = *reinterpret_cast<const bf16x8 *>(a.ln_g + i);
+      const bf16x8 t8 = *reinterpret_cast<const bf16x8 *>(a.ln_b + i);
+      // (no branch around the bias load: without a bias beta is read twice and counted once)
+      const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>((has_bias ? a.bias : a.ln_b) + i);
+      const float bsel = has_bias ? 1.0f : 0.0f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) b8[e] = (bf16)0.f;
+      for (int h = 0; h < 2; ++h) {
+        f32x4 bb, gg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bb[e] = (float)t8[h * 4 + e] + bsel * (float)b8[h * 4 + e];
+          gg[e] = (float)g8[h * 4 + e];
+        }
+        *reinterpret_cast<f32x4 *>(smem + BIAS + (i + h * 4) * 4) = bb;
+        *reinterpret_cast<f32x4 *>(smem + BIAS + 8192 + (i + h * 4) * 4) = gg;
+      }
     }
-    *reinterpret_cast<bf16x8 *>(smem + BIAS + i * 2) = b8;
+  } else {
+    for (int i = threadIdx.x * 8; i < a.tiles_n * NT; i += 256 * 8) {
+      bf16x8 b8;
+      if (has_bias) {
+        b8 = *reinterpret_cast<const bf16x8 *>(a.bias + i);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8 *>(smem + BIAS + i * 2) = b8;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1, fragments of k-step 0 ----
@@ -548,36 +664,51 @@ static int w4_cu_count() {   // of the current device
   return n;
 }
 
-template <int ACT, bool HAS_OTHER, int NJ>
+template <int ACT, bool HAS_OTHER, int NJ, int FOLD>
 static void launch_w4_act(const DenseW4Args &a, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * 128 + 4 * 4096 + 16384;   // 160 KiB
   static PerDeviceFlag attr;
   attr.once([&] {
-    (void)hipFuncSetAttribute((const void *)dense_bf16_w4_kernel<ACT, HAS_OTHER, NJ>,
+    (void)hipFuncSetAttribute((const void *)dense_bf16_w4_kernel<ACT, HAS_OTHER, NJ, FOLD>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int nt = a.tiles_m * a.tiles_n;
   int grid = w4_cu_count() & ~7;         // one workgroup per CU, a multiple of the 8 XCDs
   const int need = ((nt + 7) / 8) * 8;   // fewer tiles than CUs: one tile each
   if (grid > need) grid = need;
-  dense_bf16_w4_kernel<ACT, HAS_OTHER, NJ><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
+  dense_bf16_w4_kernel<ACT, HAS_OTHER, NJ, FOLD><<<dim3((unsigned)grid), 256, LDS, s>>>(a);
 }
 
 template <int ACT>
-static void launch_w4_other(const DenseW4Args &a, int nt_width, hipStream_t s) {
-  if (nt_width == 192) {
-    if (a.other) launch_w4_act<ACT, true, 6>(a, s);
-    else launch_w4_act<ACT, false, 6>(a, s);
+static void launch_w4_other(const DenseW4Args &a, int nt_width, int fold, hipStream_t s) {
+  if (fold == 1) {   // (mfma_bf16_dense_w4_fold_supported: no `other`)
+    if (nt_width == 192) launch_w4_act<ACT, false, 6, 1>(a, s);
+    else launch_w4_act<ACT, false, 8, 1>(a, s);
+  } else if (nt_width == 192) {
+    if (a.other) launch_w4_act<ACT, true, 6, 0>(a, s);
+    else launch_w4_act<ACT, false, 6, 0>(a, s);
   } else {
-    if (a.other) launch_w4_act<ACT, true, 8>(a, s);
-    else launch_w4_act<ACT, false, 8>(a, s);
+    if (a.other) launch_w4_act<ACT, true, 8, 0>(a, s);
+    else launch_w4_act<ACT, false, 8, 0>(a, s);
   }
+}
+
+bool mfma_bf16_dense_w4_fold_supported(const DenseFold &f, int act, int combine,
+                                       const void *other, int64_t N) {
+  if (f.mode == 1)
+    return !other && f.rstats && f.c && f.b && ((uintptr_t)f.c | (uintptr_t)f.b) % 16 == 0 &&
+           (uintptr_t)f.rstats % 8 == 0;
+  if (f.mode == 2)   // (N <= 2048: the fp32 bias + beta / gamma images share the 16 KiB bias region)
+    return N <= 2048 && other && combine == GNLP_COMBINE_ADD && act == GNLP_ACT_IDENTITY && f.rstats &&
+           f.ln_g && f.ln_b && ((uintptr_t)f.ln_g | (uintptr_t)f.ln_b) % 16 == 0 &&
+           (uintptr_t)f.rstats % 8 == 0;
+  return f.mode == 0;
 }
 
 void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const void *bias,
                                const void *other, int combine, int act, int64_t M, int64_t N,
                                int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
-                               hipStream_t s) {
+                               hipStream_t s, const DenseFold *fold) {
   DenseW4Args a;
   a.x = (const bf16 *)x; a.w = (const bf16 *)w; a.bias = (const bf16 *)bias;
   a.other = (const bf16 *)other; a.out = (bf16 *)out;
@@ -585,14 +716,25 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   a.K = (int)K; a.nk = (int)(K >> 6); a.combine = combine;
   a.tiles_m = (int)(M / 256);
   a.rows_dev = dense_rows_dev();
+  const int mode = fold ? fold->mode : 0;
+  a.rstats = mode ? fold->rstats : nullptr;
+  a.fold_c = mode == 1 ? fold->c : nullptr;
+  a.fold_b = mode == 1 ? fold->b : nullptr;
+  a.ln_g = mode == 2 ? (const bf16 *)fold->ln_g : nullptr;
+  a.ln_b = mode == 2 ? (const bf16 *)fold->ln_b : nullptr;
   const int width = w4_tile_width(M, N, w4_cu_count() & ~7, a.rows_dev != nullptr);
   a.tiles_n = (int)(N / width);
   a.group_m = knobs().group_m;
+  if (mode == 2) {   // residual = LayerNorm(other): identity activation, add
+    if (width == 192) launch_w4_act<GNLP_ACT_IDENTITY, true, 6, 2>(a, s);
+    else launch_w4_act<GNLP_ACT_IDENTITY, true, 8, 2>(a, s);
+    return;
+  }
   switch (act) {
-    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, width, s); break;
-    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, width, s); break;
-    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, width, s); break;
-    default: launch_w4_other<GNLP_ACT_IDENTITY>(a, width, s); break;
+    case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, width, mode, s); break;
+    case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, width, mode, s); break;
+    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, width, mode, s); break;
+    default: launch_w4_other<GNLP_ACT_IDENTITY>(a, width, mode, s); break;
   }
 }
 

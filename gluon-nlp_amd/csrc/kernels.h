@@ -37,6 +37,7 @@ struct Knobs {
   bool norm_full;   // GNLP_NORM_MAXV=f: always the full-width register image
   bool pack_ragged; // GNLP_PACK_RAGGED=0: the stack drivers never pack a ragged batch
   bool attn_bwd_bf16; // GNLP_ATTN_BWD_BF16=0: attention backward on the fp32 matrix cores for bf16 too
+  bool ln_fold;     // GNLP_LN_FOLD=0: stacks never run with their LayerNorms folded into the GEMMs
   int skinny_max_m; // GNLP_SKINNY_MAX_M: bf16 Dense calls with at most this many rows take the
                     // K-split kernel (gemm_bf16.hip); 0 = never
 };
@@ -102,6 +103,15 @@ void launch_norm(void *out, const void *x, const void *residual, const void *gam
                  const void *vl, int vl_dtype, int64_t B, int64_t L, int time_major,
                  hipStream_t s);
 
+// LayerNorm folded into the GEMMs around it (norm.hip): row statistics (r, r * mean) of bf16 rows,
+// and the folded parameters (wf, c, bf) of the Dense that consumes the norm (see DenseFold)
+bool row_stats_supported(int64_t C, const void *x);
+void launch_row_stats(float *rstats, const void *x, float eps, int64_t rows, int64_t C,
+                      hipStream_t s);
+void launch_fold_norm_dense(void *wf, float *c, float *bfold, const void *w, const void *b,
+                            const void *gamma, const void *beta, int64_t N, int64_t K,
+                            int64_t n_scaled, float scale, hipStream_t s);
+
 // softmax.hip
 void launch_masked_softmax(void *out, const void *scores, int dtype, const uint8_t *mask,
                            const int64_t mask_stride[4], const int64_t shape[4],
@@ -133,6 +143,19 @@ bool mfma_bf16_dense_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int
 void launch_mfma_bf16_dense(void *out, const void *x, const void *w, const void *bias,
                             const void *other, int combine, int act, int64_t M, int64_t N,
                             int64_t K, int64_t ldx, int64_t ldo, int64_t ldother, hipStream_t s);
+// A LayerNorm folded into the bf16 GEMMs around it (persistent kernel only).
+// For a row with statistics mu, r = rsqrt(var + eps):  LN(s) . W^T + b  =
+//   r (s . W'^T) - (r mu) c + b'   with W' = bf16(gamma * W), c[n] = sum_k W'[n, k], b' = beta . W^T + b
+struct DenseFold {
+  int mode;              // 0 none
+                         // 1 x holds the raw sums s and w the folded weights: out = act(r acc - (r mu) c + b')
+                         // 2 `other` holds raw sums: out = acc + bias + gamma (r s - r mu) + beta
+  const float *rstats;   // (rows, 2) fp32: r, r * mu of the rows of x (mode 1) / of `other` (mode 2)
+  const float *c, *b;    // mode 1: (N) fp32
+  const void *ln_g, *ln_b;   // mode 2: (N) bf16
+};
+bool mfma_bf16_dense_w4_fold_supported(const DenseFold &f, int act, int combine, const void *other,
+                                       int64_t N);
 // One-wave-per-SIMD form (gemm_bf16_w4.hip): PERSISTENT, 4 waves of 128x128; M a multiple of 256,
 // N a multiple of 256 or of 192 (256x192 tiles, 4 waves of 128x96).
 bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldo,
@@ -141,7 +164,7 @@ bool mfma_bf16_dense_w4_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, 
 void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const void *bias,
                                const void *other, int combine, int act, int64_t M, int64_t N,
                                int64_t K, int64_t ldx, int64_t ldo, int64_t ldother,
-                               hipStream_t s);
+                               hipStream_t s, const DenseFold *fold = nullptr);
 bool mfma_bf16_dense_pp_supported(int64_t N, int64_t ldo, int64_t ldother, const void *out,
                                   const void *bias, const void *other);
 void launch_mfma_bf16_dense_pp(void *out, const void *x, const void *w, const void *bias,

@@ -200,4 +200,115 @@ void launch_norm(void *out, const void *x, const void *residual, const void *gam
                   time_major, s);
 }
 
+// ---- LayerNorm folded into the GEMMs around it (bf16 post-norm stacks) ----
+// Row statistics of the raw pre-norm sums: r = rsqrt(var + eps) and r * mean per row, fp32, with
+// the same two-pass formulation as norm_vec_kernel (the row stays in registers).  Read-only over
+// the rows: 2 bytes per element in, 8 bytes per row out.
+template <int MAXV>
+__global__ void __launch_bounds__(256)
+row_stats_kernel(float *__restrict__ rstats, const bf16 *__restrict__ x, float eps, int64_t rows,
+                 int C, const int32_t *__restrict__ rows_dev) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  if (rows_dev && row >= *rows_dev) return;
+  const int nvec = C / 8;
+  const bf16 *xr = x + row * (int64_t)C;
+  float vals[MAXV][8];
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nvec) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8 *>(xr + v * 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        vals[i][q] = (float)a[q];
+        sum += vals[i][q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) vals[i][q] = 0.0f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float ss = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (lane + i * 64 < nvec) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float d = vals[i][q] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+  if (lane == 0) *reinterpret_cast<f32x2 *>(rstats + row * 2) = (f32x2){rstd, rstd * mean};
+}
+
+bool row_stats_supported(int64_t C, const void *x) {
+  return C % 8 == 0 && C <= 2048 && (uintptr_t)x % 16 == 0;
+}
+
+void launch_row_stats(float *rstats, const void *x, float eps, int64_t rows, int64_t C,
+                      hipStream_t s) {
+  if (rows == 0) return;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (C <= 1024)
+    row_stats_kernel<2><<<grid, 256, 0, s>>>(rstats, (const bf16 *)x, eps, rows, (int)C,
+                                             dense_rows_dev());
+  else
+    row_stats_kernel<4><<<grid, 256, 0, s>>>(rstats, (const bf16 *)x, eps, rows, (int)C,
+                                             dense_rows_dev());
+}
+
+// The folded parameters of a Dense that consumes LayerNorm(s) (run once per parameter version):
+//   wf[n, k] = bf16(gamma[k] w[n, k] sc_n),  c[n] = sum_k float(wf[n, k]),
+//   bf[n] = (sum_k beta[k] w[n, k] + b[n]) sc_n,        sc_n = scale for n < n_scaled, else 1
+// c sums the ROUNDED folded weights, so that sum_k (s_k - mu) wf[n, k] = s . wf[n, :] - mu c[n]
+// holds exactly in the arithmetic of the GEMM.  One wave per output row n.
+__global__ void __launch_bounds__(256)
+fold_norm_dense_kernel(bf16 *__restrict__ wf, float *__restrict__ c, float *__restrict__ bfold,
+                       const bf16 *__restrict__ w, const bf16 *__restrict__ b,
+                       const bf16 *__restrict__ gamma, const bf16 *__restrict__ beta, int64_t N,
+                       int64_t K, int64_t n_scaled, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float sc = n < n_scaled ? scale : 1.0f;
+  const bf16 *wr = w + n * K;
+  bf16 *wo = wf + n * K;
+  float csum = 0.0f, bsum = 0.0f;
+  for (int64_t k = (int64_t)lane * 8; k < K; k += 64 * 8) {
+    const bf16x8 w8 = *reinterpret_cast<const bf16x8 *>(wr + k);
+    const bf16x8 g8 = *reinterpret_cast<const bf16x8 *>(gamma + k);
+    bf16x8 t8, o8;
+    if (beta) t8 = *reinterpret_cast<const bf16x8 *>(beta + k);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float wv = (float)w8[e];
+      o8[e] = (bf16)((float)g8[e] * wv * sc);
+      csum += (float)o8[e];
+      if (beta) bsum += (float)t8[e] * wv;
+    }
+    *reinterpret_cast<bf16x8 *>(wo + k) = o8;
+  }
+  csum = wave_sum(csum);
+  bsum = wave_sum(bsum);
+  if (lane == 0) {
+    c[n] = csum;
+    bfold[n] = (bsum + (b ? (float)b[n] : 0.0f)) * sc;
+  }
+}
+
+void launch_fold_norm_dense(void *wf, float *c, float *bfold, const void *w, const void *b,
+                            const void *gamma, const void *beta, int64_t N, int64_t K,
+                            int64_t n_scaled, float scale, hipStream_t s) {
+  if (N == 0) return;
+  fold_norm_dense_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(
+      (bf16 *)wf, c, bfold, (const bf16 *)w, (const bf16 *)b, (const bf16 *)gamma,
+      (const bf16 *)beta, N, K, n_scaled, scale);
+}
+
 }  // namespace gnlp

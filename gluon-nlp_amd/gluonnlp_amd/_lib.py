@@ -54,6 +54,11 @@ class EncoderLayerParams(Structure):
                 ('proj_b', c_void_p), ('ln_g', c_void_p), ('ln_b', c_void_p), ('ffn', FfnParams)]
 
 
+class EncoderLayerFolded(Structure):
+    _fields_ = [('qkv_wf', c_void_p), ('qkv_c', c_void_p), ('qkv_bf', c_void_p),
+                ('ffn1_wf', c_void_p), ('ffn1_c', c_void_p), ('ffn1_bf', c_void_p)]
+
+
 class EncoderCfg(Structure):
     _fields_ = [('units', c_int64), ('hidden', c_int64), ('heads', c_int64), ('act', c_int),
                 ('pre_norm', c_int), ('dtype', c_int), ('time_major', c_int), ('ln_eps', c_float)]
@@ -163,6 +168,15 @@ PROTOTYPES = {
                                            POINTER(EncoderCfg), c_int64, c_int64, c_void_p, c_int,
                                            c_int, POINTER(c_void_p), c_void_p, c_size_t,
                                            c_void_p]),
+    'gnlp_encoder_stack_forward_folded': (c_int, [c_void_p, c_void_p, POINTER(EncoderLayerParams),
+                                                  POINTER(EncoderLayerFolded), c_int,
+                                                  POINTER(EncoderCfg), c_int64, c_int64, c_void_p,
+                                                  c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'gnlp_stack_last_folded': (c_int, []),
+    'gnlp_fold_norm_dense': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_int64, c_int64, c_int64, c_float,
+                                     c_void_p]),
+    'gnlp_row_stats': (c_int, [c_void_p, c_void_p, c_int, c_float, c_int64, c_int64, c_void_p]),
     'gnlp_t5_workspace_bytes': (c_size_t, [POINTER(T5Cfg), c_int64, c_int64]),
     'gnlp_t5_encoder_forward': (c_int, [c_void_p, c_void_p, POINTER(T5BlockParams), c_int,
                                         c_void_p, c_void_p, POINTER(T5Cfg), c_int64, c_int64,

@@ -15,6 +15,7 @@ from ..attention_cell import (MultiHeadAttentionCell, gen_mem_attn_mask, gen_sel
 from ..layers import Dense, LayerNorm, PositionwiseFFN, ffn_params_struct, memory_kv
 
 __all__ = ['TransformerEncoderLayer', 'TransformerEncoder', 'run_encoder_stack',
+           'drop_folded_parameters',
            'TransformerDecoderLayer', 'TransformerDecoder']
 
 
@@ -130,6 +131,83 @@ class TransformerEncoderLayer(nn.Module):
         return T.like_caller(out, data), (T.like_caller(w, data) if w is not None else None)
 
 
+# ---- LayerNorms folded into the GEMMs around them (bf16 post-norm stacks) ---------------------
+# gnlp_encoder_stack_forward_folded takes, per layer, the folded parameters of attn_qkv (with the
+# PREVIOUS layer's ffn.layer_norm) and of ffn.ffn_1 (with this layer's layer_norm).  They are a
+# function of the parameters only, computed on the device once per parameter version and kept with
+# the first layer of the stack.  The key is (data_ptr, _version) of every tensor involved: an
+# optimizer step, load_state_dict or `p.data = ...` change it; an in-place write through `.data`
+# (`p.data.copy_(...)`) changes neither -- call drop_folded_parameters(layers) after such an edit
+# (or set GNLP_LN_FOLD=0).
+_FOLD_ATTR = '_gnlp_folded_params'
+
+
+def drop_folded_parameters(layers):
+    """Forget the folded LayerNorm parameters of a stack (a list of TransformerEncoderLayers, or a
+    module that contains them): the next forward recomputes them."""
+    mods = layers.modules() if isinstance(layers, nn.Module) else layers
+    for m in mods:
+        if hasattr(m, _FOLD_ATTR):
+            delattr(m, _FOLD_ATTR)
+
+
+def _fold_sources(layers):
+    for ly in layers:
+        for t in (ly.attn_qkv.weight, ly.attn_qkv.bias, ly.layer_norm.gamma, ly.layer_norm.beta,
+                  ly.ffn.ffn_1.weight, ly.ffn.ffn_1.bias, ly.ffn.layer_norm.gamma,
+                  ly.ffn.layer_norm.beta):
+            yield t
+
+
+def _fold_key(layers):
+    return tuple(None if t is None else (t.data_ptr(), t._version) for t in _fold_sources(layers))
+
+
+def _folded_params(layers, dev):
+    """(ctypes array, tensors kept alive) or None when the stack cannot fold at all."""
+    l0 = layers[0]
+    if l0.attn_qkv.weight.dtype != torch.bfloat16 or l0._pre_norm:
+        return None
+    for ly in layers:
+        if ly._pre_norm or ly.ffn._pre_norm or ly.ffn._use_gated_activation or \
+                not isinstance(ly.ffn.layer_norm, LayerNorm):
+            return None
+        if ly.layer_norm.beta is None or ly.ffn.layer_norm.beta is None:
+            return None
+    key = _fold_key(layers)
+    cached = getattr(l0, _FOLD_ATTR, None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    lib = _lib.load()
+    stream = T.stream(dev)
+    keep = []
+    n = len(layers)
+    arr = (_lib.EncoderLayerFolded * n)()
+
+    def fold(dense, norm):
+        w = dense.weight.data.contiguous()
+        N, K = w.shape
+        wf = torch.empty_like(w)
+        c = torch.empty(N, dtype=torch.float32, device=dev)
+        bf = torch.empty(N, dtype=torch.float32, device=dev)
+        _lib.check(lib.gnlp_fold_norm_dense(
+            T.ptr(wf), T.ptr(c), T.ptr(bf), T.ptr(w),
+            T.ptr(dense.bias.data) if dense.bias is not None else None, T.ptr(norm.gamma.data),
+            T.ptr(norm.beta.data), _lib.BF16, N, K, 0, 1.0, stream))
+        keep.extend([wf, c, bf])
+        return T.ptr(wf), T.ptr(c), T.ptr(bf)
+
+    for i, ly in enumerate(layers):
+        if i > 0:
+            arr[i].qkv_wf, arr[i].qkv_c, arr[i].qkv_bf = fold(ly.attn_qkv, layers[i - 1].ffn.layer_norm)
+        arr[i].ffn1_wf, arr[i].ffn1_c, arr[i].ffn1_bf = fold(ly.ffn.ffn_1, ly.layer_norm)
+    # (the entry also holds the source storages: while it lives, no other tensor can be handed
+    # their addresses, so an equal data_ptr means the same memory)
+    keep.extend(t.data for t in _fold_sources(layers) if t is not None)
+    setattr(l0, _FOLD_ATTR, (key, arr, keep))
+    return arr, keep
+
+
 def run_encoder_stack(layers, data, valid_length, layout, final_seq_mask, all_encodings=False):
     """Run a list of post-/pre-norm TransformerEncoderLayers back to back in ONE C call
     (gnlp_encoder_stack_forward); the mask is the valid_length predicate evaluated in-kernel."""
@@ -158,10 +236,19 @@ def run_encoder_stack(layers, data, valid_length, layout, final_seq_mask, all_en
         outs = torch.empty_like(x)
         ptrs = None
         out_ptr = T.ptr(outs)
-    _lib.check(lib.gnlp_encoder_stack_forward(
-        out_ptr, T.ptr(x), arr, n, ctypes.byref(cfg), B, L, vlp, vlc,
-        int(bool(final_seq_mask) and vlp is not None), ptrs, T.ptr(ws),
-        0 if ws is None else ws.numel(), T.stream(dev)))
+    folded = None
+    if not all_encodings and x.dtype == torch.bfloat16 and (B * L) % 256 == 0:
+        folded = _folded_params(layers, dev)
+    if folded is not None:   # (the C side falls back to the plain stack for shapes it cannot fold)
+        _lib.check(lib.gnlp_encoder_stack_forward_folded(
+            out_ptr, T.ptr(x), arr, folded[0], n, ctypes.byref(cfg), B, L, vlp, vlc,
+            int(bool(final_seq_mask) and vlp is not None), T.ptr(ws),
+            0 if ws is None else ws.numel(), T.stream(dev)))
+    else:
+        _lib.check(lib.gnlp_encoder_stack_forward(
+            out_ptr, T.ptr(x), arr, n, ctypes.byref(cfg), B, L, vlp, vlc,
+            int(bool(final_seq_mask) and vlp is not None), ptrs, T.ptr(ws),
+            0 if ws is None else ws.numel(), T.stream(dev)))
     if all_encodings:
         return [T.like_caller(o, data) for o in outs]
     return T.like_caller(outs, data)

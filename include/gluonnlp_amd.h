@@ -449,6 +449,44 @@ int gnlp_encoder_stack_forward(void *out, const void *x, const gnlp_encoder_laye
                                void *const *all_encodings, void *workspace, size_t workspace_bytes,
                                gnlp_stream_t stream);
 
+/* The same stacks with their LayerNorms FOLDED into the GEMMs around them (bf16, post-norm; no
+ * counterpart in the reference, whose layers run nn.LayerNorm as an operator of its own,
+ * models/transformer.py:268-270, layers.py:642-646 -- same arithmetic regrouped).  For a row s with
+ * mean mu and r = rsqrt(var + eps):
+ *     LayerNorm(s) . W^T + b  =  r (s . W'^T) - (r mu) c + b',
+ *     W' = bf16(gamma * W),  c[n] = sum_k W'[n, k],  b'[n] = sum_k beta[k] W[n, k] + b[n],
+ * so attn_qkv and ffn_1 take the RAW sums as their A operand and apply the two per-row scalars in
+ * the GEMM drain, and the residual operands of attention_proj / ffn_2 (= LayerNorm(s)) are rebuilt
+ * in their drains from s, the statistics and gamma / beta.  The normalised tensors are never
+ * written; only the last layer's norm (+ sequence mask) runs as a kernel.
+ *
+ * gnlp_fold_norm_dense computes (W', c, b') of one Dense on the device; call it once per
+ * parameter version.  The first n_scaled output rows are additionally multiplied by `scale`
+ * (pass 0 / 1.0f for none).  gnlp_row_stats writes (r, r * mu) per row, fp32, shape (rows, 2).
+ * A stack whose shapes the folded kernels do not take (rows not a multiple of 256, units > 2048,
+ * a GEMM that is not on the persistent kernel, ...) runs exactly as gnlp_encoder_stack_forward;
+ * gnlp_stack_last_folded() tells which.  GNLP_LN_FOLD=0 switches the folded path off. */
+typedef struct {
+  const void *qkv_wf;              /* attn_qkv folded with the PREVIOUS layer's ffn.layer_norm */
+  const float *qkv_c, *qkv_bf;     /*   (3U, U) bf16, (3U) fp32 x 2; ignored for the first layer */
+  const void *ffn1_wf;             /* ffn.ffn_1 folded with this layer's layer_norm */
+  const float *ffn1_c, *ffn1_bf;   /*   (F, U) bf16, (F) fp32 x 2 */
+} gnlp_encoder_layer_folded;
+
+int gnlp_fold_norm_dense(void *wf, float *c, float *bf, const void *w, const void *b,
+                         const void *gamma, const void *beta, int dtype, int64_t N, int64_t K,
+                         int64_t n_scaled, float scale, gnlp_stream_t stream);
+int gnlp_row_stats(float *rstats, const void *x, int dtype, float eps, int64_t rows, int64_t C,
+                   gnlp_stream_t stream);
+int gnlp_encoder_stack_forward_folded(void *out, const void *x,
+                                      const gnlp_encoder_layer_params *layers,
+                                      const gnlp_encoder_layer_folded *folded, int n_layers,
+                                      const gnlp_encoder_cfg *cfg, int64_t B, int64_t L,
+                                      const void *valid_length, int vl_dtype, int final_seq_mask,
+                                      void *workspace, size_t workspace_bytes,
+                                      gnlp_stream_t stream);
+int gnlp_stack_last_folded(void);
+
 /* T5Block.forward (encoder) / T5Encoder.forward   models/t5.py:492-572, 666-711 */
 typedef struct {
   const void *attn_ln_g, *attn_ln_b;     /* self_attn_layer_norm.gamma / .beta (beta may be NULL) */

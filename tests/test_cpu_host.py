@@ -40,7 +40,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     structs = {'gnlp_attn_desc': _lib.AttnDesc, 'gnlp_ffn_params': _lib.FfnParams,
                'gnlp_ffn_cfg': _lib.FfnCfg, 'gnlp_encoder_layer_params': _lib.EncoderLayerParams,
                'gnlp_encoder_cfg': _lib.EncoderCfg, 'gnlp_t5_block_params': _lib.T5BlockParams,
-               'gnlp_t5_cfg': _lib.T5Cfg}
+               'gnlp_t5_cfg': _lib.T5Cfg, 'gnlp_encoder_layer_folded': _lib.EncoderLayerFolded}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gluonnlp_amd.h"',
              'int main(void) {']
     for cname, cls in structs.items():
@@ -213,9 +213,11 @@ def test_one_wave_per_simd_gemm_static_checks(tmp_path):
                     '--cuda-device-only', '-o', asm, src], check=True, capture_output=True)
     text = open(asm).read()
     names = re.findall(r'\.name:\s+(_ZN4gnlp20dense_bf16_w4_kernel\w+)', text)
-    assert len(names) == 16
-    narrow = [n.endswith('Li6EEEvNS_11DenseW4ArgsE') for n in names]   # NJ = 6: 256x192 tiles
-    assert sum(narrow) == 8
+    # 4 activations x {residual, none} x {256, 192 wide} + the instantiations with a LayerNorm
+    # folded in: 4 activations x 2 widths (FOLD 1) and the identity + residual x 2 widths (FOLD 2)
+    assert len(names) == 26
+    narrow = [re.search(r'Li6ELi\dEEEvNS_11DenseW4ArgsE$', n) is not None for n in names]   # NJ = 6
+    assert sum(narrow) == 13
     for key, want in [('vgpr_spill_count', 0), ('sgpr_spill_count', 0),
                       ('private_segment_fixed_size', 0)]:
         vals = [int(v) for v in re.findall(r'\.%s:\s+(\d+)' % key, text)]

@@ -1,6 +1,6 @@
 """Static check of the persistent GEMM's hand-counted global loads (developer tool).
 
-For every inline-asm `global_load_dwordx4 v[a:b], ...` in the dense_bf16_w4 kernels of an
+For every inline-asm `global_load_dwordx4 / dwordx2 v[a:b], ...` in the dense_bf16_w4 kernels of an
 assembly listing, the first later instruction that names one of v[a..b] must come AFTER an
 `s_waitcnt vmcnt(...)`: the compiler believes the asm output is valid at once, so a copy or a
 use placed before the wait would read the register before the load has landed.
@@ -32,7 +32,7 @@ def main(path):
         if kernel is None:
             continue
         t = ln.strip()
-        if not t.startswith('global_load_dwordx4'):
+        if not (t.startswith('global_load_dwordx4') or t.startswith('global_load_dwordx2')):
             continue
         dst = regs_of(t.split()[1].rstrip(','))
         checked += 1
