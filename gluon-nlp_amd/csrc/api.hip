@@ -590,8 +590,8 @@ int encoder_layer_folded(void *out, const void *x, const void *raw_in, const flo
                          const gnlp_encoder_layer_params *prev, const gnlp_encoder_layer_params *p,
                          const gnlp_encoder_layer_folded *f, const gnlp_encoder_cfg *c, int64_t B,
                          int64_t L, const void *vl, int vl_dtype, int final_seq_mask, bool last,
-                         void *raw_out, float *rs_mid, float *rs_out, void *ws, size_t ws_bytes,
-                         hipStream_t s, const int32_t *cu) {
+                         void *raw_out, float *rs_mid, float *rs_out, float *part, void *ws,
+                         size_t ws_bytes, hipStream_t s, const int32_t *cu) {
   const int64_t U = c->units, H = c->heads, M = B * L, d = U / H, F = c->hidden;
   const EncWs w = enc_ws(c, B, L, false);
   REQUIRE(ws && ws_bytes >= w.total, "encoder workspace too small: need %zu bytes, got %zu",
@@ -605,7 +605,7 @@ int encoder_layer_folded(void *out, const void *x, const void *raw_in, const flo
     rc = dense_impl(qkv, x, p->qkv_w, p->qkv_b, nullptr, 0, GNLP_ACT_IDENTITY, c->dtype, M, 3 * U,
                     U, U, 3 * U, 0, s);
   } else {   // attn_qkv(LN(raw_in))
-    fd = DenseFold{1, rs_in, f->qkv_c, f->qkv_bf, nullptr, nullptr};
+    fd = DenseFold{1, rs_in, f->qkv_c, f->qkv_bf, nullptr, nullptr, nullptr};
     rc = dense_impl(qkv, raw_in, f->qkv_wf, nullptr, nullptr, 0, GNLP_ACT_IDENTITY, c->dtype, M,
                     3 * U, U, U, 3 * U, 0, s, &fd);
   }
@@ -627,20 +627,22 @@ int encoder_layer_folded(void *out, const void *x, const void *raw_in, const flo
   if (!raw_in) {
     rc = dense_impl(base + w.sum, base + w.ctx, p->proj_w, p->proj_b, x, GNLP_COMBINE_ADD,
                     GNLP_ACT_IDENTITY, c->dtype, M, U, U, U, U, U, s);
-  } else {
-    fd = DenseFold{2, rs_in, nullptr, nullptr, prev->ffn.ln_g, prev->ffn.ln_b};
+    if (rc) return rc;
+    launch_row_stats(rs_mid, base + w.sum, c->ln_eps, M, U, s);   // (a plain residual: one read)
+  } else {   // the drain leaves partial row sums of its output: no pass over the sum
+    fd = DenseFold{2, rs_in, nullptr, nullptr, prev->ffn.ln_g, prev->ffn.ln_b, part};
     rc = dense_impl(base + w.sum, base + w.ctx, p->proj_w, p->proj_b, raw_in, GNLP_COMBINE_ADD,
                     GNLP_ACT_IDENTITY, c->dtype, M, U, U, U, U, U, s, &fd);
+    if (rc) return rc;
+    launch_stats_finish(rs_mid, part, fold_stat_slots(M, U), c->ln_eps, M, U, s);
   }
-  if (rc) return rc;
-  launch_row_stats(rs_mid, base + w.sum, c->ln_eps, M, U, s);
   // hidden = act(ffn_1(LN(sum)));  raw_out = ffn_2(hidden) + LN(sum)
   void *hidden = base + w.ffn;   // (ffn_ws of a post-norm, ungated FFN: hidden first)
-  fd = DenseFold{1, rs_mid, f->ffn1_c, f->ffn1_bf, nullptr, nullptr};
+  fd = DenseFold{1, rs_mid, f->ffn1_c, f->ffn1_bf, nullptr, nullptr, nullptr};
   rc = dense_impl(hidden, base + w.sum, f->ffn1_wf, nullptr, nullptr, 0, c->act, c->dtype, M, F, U,
                   U, F, 0, s, &fd);
   if (rc) return rc;
-  fd = DenseFold{2, rs_mid, nullptr, nullptr, p->ln_g, p->ln_b};
+  fd = DenseFold{2, rs_mid, nullptr, nullptr, p->ln_g, p->ln_b, part};
   rc = dense_impl(raw_out, hidden, p->ffn.ffn2_w, p->ffn.ffn2_b, base + w.sum, GNLP_COMBINE_ADD,
                   GNLP_ACT_IDENTITY, c->dtype, M, U, F, F, U, U, s, &fd);
   if (rc) return rc;
@@ -648,9 +650,14 @@ int encoder_layer_folded(void *out, const void *x, const void *raw_in, const flo
     launch_norm(out, raw_out, nullptr, p->ffn.ln_g, p->ffn.ln_b, c->dtype, GNLP_NORM_LAYER,
                 c->ln_eps, M, U, final_seq_mask ? vl : nullptr, vl_dtype, B, L, c->time_major, s);
   } else {
-    launch_row_stats(rs_out, raw_out, c->ln_eps, M, U, s);
+    launch_stats_finish(rs_out, part, fold_stat_slots(M, U), c->ln_eps, M, U, s);
   }
   return check_launch("folded encoder layer");
+}
+
+// partial row sums a folded GEMM's drain leaves: 4 (sum, sum of squares) pairs per tile column
+size_t fold_part_bytes(int64_t M, int64_t U) {
+  return align256((size_t)M * 4 * ((U + 191) / 192) * 2 * sizeof(float));
 }
 
 int check_encoder_cfg(const gnlp_encoder_cfg *c, int64_t B, int64_t L) {
@@ -1162,7 +1169,8 @@ size_t gnlp_encoder_workspace_bytes(const gnlp_encoder_cfg *cfg, int64_t B, int6
   // (+ two (rows, 2) fp32 row-statistics vectors of a stack run with folded LayerNorms)
   return enc_ws(cfg, B, L, want_weights != 0).total +
          2 * align256((size_t)B * L * cfg->units * esize(cfg->dtype)) +
-         align256((size_t)(B + 2) * sizeof(int32_t)) + 2 * align256((size_t)B * L * 2 * sizeof(float));
+         align256((size_t)(B + 2) * sizeof(int32_t)) + 2 * align256((size_t)B * L * 2 * sizeof(float)) +
+         fold_part_bytes(B * L, cfg->units);
 }
 
 int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_layer_params *p,
@@ -1297,11 +1305,13 @@ static int encoder_stack_impl(void *out, const void *x, const gnlp_encoder_layer
   // as a kernel.  Needs the caller's folded parameters and the persistent GEMM for all four shapes.
   const size_t rs_bytes = align256((size_t)B * L * 2 * sizeof(float));
   if (folded && !all_encodings && knobs().ln_fold &&
-      workspace_bytes >= layer_bytes + 2 * act_bytes + cu_bytes + 2 * rs_bytes &&
+      workspace_bytes >= layer_bytes + 2 * act_bytes + cu_bytes + 2 * rs_bytes +
+                             fold_part_bytes(B * L, cfg->units) &&
       stack_can_fold(cfg, B, L, base, layers, folded, n_layers)) {
     hipStream_t s = S(stream);
     float *rs[2] = {(float *)(base + layer_bytes + 2 * act_bytes + cu_bytes),
                     (float *)(base + layer_bytes + 2 * act_bytes + cu_bytes + rs_bytes)};
+    float *part = (float *)(base + layer_bytes + 2 * act_bytes + cu_bytes + 2 * rs_bytes);
     void *raw = base + enc_ws(cfg, B, L, false).x1;   // (the materialised LN(sum) of the plain path)
     const bool pack = valid_length && final_seq_mask && knobs().pack_ragged &&
                       stack_can_pack(cfg, B, L, base, layers, n_layers);
@@ -1325,7 +1335,7 @@ static int encoder_stack_impl(void *out, const void *x, const gnlp_encoder_layer
       const bool last = i == n_layers - 1;
       rc = encoder_layer_folded(dst, x0, i ? raw : nullptr, rs[1], i ? &layers[i - 1] : nullptr, p,
                                 &folded[i], cfg, B, L, valid_length, vl_dtype,
-                                pack ? 0 : final_seq_mask, last, raw, rs[0], rs[1], base,
+                                pack ? 0 : final_seq_mask, last, raw, rs[0], rs[1], part, base,
                                 layer_bytes, s, cu);
       if (rc) return rc;
     }

@@ -76,6 +76,9 @@ struct DenseW4Args {
   const float *rstats;       // (rows, 2): r = rsqrt(var + eps) and r * mean of the row's raw sum
   const float *fold_c, *fold_b;   // FOLD == 1: c[n] = sum_k w'[n, k], b'[n] = beta . w[n, :] + b[n]
   const bf16 *ln_g, *ln_b;        // FOLD == 2: gamma / beta of the norm `other` goes through
+  float *stats_part;              // FOLD == 2: (rows, 4 * tiles_n, 2) partial (sum, sum of squares)
+                                  // of the OUTPUT rows, one slot per 64-column group of a tile
+                                  // (plain stores, no atomics: a fixed summation order downstream)
 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -128,6 +131,14 @@ constexpr int w4_find(const int *tab, int n, int t) {
   for (int q = 0; q < n; ++q)
     if (tab[q] == t) return q;
   return -1;
+}
+
+// sum over the 8 lanes that share (lane >> 3): xor 1, xor 2 inside the quad, then the mirrored quad
+__device__ __forceinline__ float w4_oct_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+  return x;
 }
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
@@ -278,6 +289,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
       if constexpr (t == S::BAR2 && !FIRST) W4_STAMP_AT(4);
       if constexpr (ib >= 0) stage_b(X, pB, ib);
       if constexpr (t == S::BAR3 - 1) {   // the requests of THIS K-tile issued so far may fly on
+        // (a larger allowance in a tile's first K-tile, for the drain's stores that are younger
+        // than the K-tile waited for, measured +-0: rounds 1 and 3)
         constexpr int NFLY = w4_count_le(S::SA, 8, t) + w4_count_le(S::SB, NJ, t);
         if constexpr (!FIRST) W4_STAMP_AT(5);
         W4_SB();
@@ -313,6 +326,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   constexpr bool RING = HAS_OTHER || FOLD != 0;
   constexpr int NL = (HAS_OTHER ? 4 : 0) + (FOLD != 0 ? 4 : 0);   // operations of one L group
   constexpr int RD = FOLD == 2 ? 2 : 3;   // ring depth (FOLD 2 holds both rings: registers)
+  constexpr int NST = FOLD == 2 ? 8 : 4;  // stores of one S group (FOLD 2: + the rows' statistics)
   auto drain = [&](int m0, int n0) __attribute__((always_inline)) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
@@ -355,10 +369,10 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     auto slab_wait = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       // RD 3: L0 L1 | L2 [wait L0] S0 | L3 [wait L1] S1 | ... | [wait L6] S6 | [wait L7] S7
-      // RD 2: L0 | L1 [wait L0] S0 | L2 [wait L1] S1 | ... | [wait L7] S7      (S groups: 4 stores)
-      constexpr int FLY = RD == 3 ? (k == 0 ? 2 * NL : k == 1 ? 2 * NL + 4 : k <= 5 ? 2 * NL + 8
-                                                                : k == 6 ? NL + 8 : 8)
-                                  : (k + 1 < 8 ? NL : 0) + (k >= 1 ? 4 : 0);
+      // RD 2: L0 | L1 [wait L0] S0 | L2 [wait L1] S1 | ... | [wait L7] S7    (S groups: NST stores)
+      constexpr int FLY = RD == 3 ? (k == 0 ? 2 * NL : k == 1 ? 2 * NL + NST
+                                     : k <= 5 ? 2 * NL + 2 * NST : k == 6 ? NL + 2 * NST : 2 * NST)
+                                  : (k + 1 < 8 ? NL : 0) + (k >= 1 ? NST : 0);
       bf16x8(&r)[2][2] = ring[k % RD];
       f32x2(&t)[2][2] = ringst[k % RD];
       if constexpr (HAS_OTHER && FOLD != 0)
@@ -497,7 +511,24 @@ dense_bf16_w4_kernel(DenseW4Args a) {
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
             if (NJ == 8 || on)
               *reinterpret_cast<bf16x8 *>(a.out + (mrow + q * 16 + it * 8) * a.ldo + n) = o;
-            if constexpr (FOLD == 2) W4_SB();   // one row at a time: registers (no spills)
+            if constexpr (FOLD == 2) {
+              // statistics of the output row for the LayerNorm the NEXT GEMMs fold in: this
+              // lane's 8 columns, then the 8 lanes of the row; one (sum, sum of squares) per row
+              // and 64-column group, summed in a fixed order by stats_finish_kernel
+              float ps = 0.0f, pq = 0.0f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                ps += v[e];
+                pq = __builtin_fmaf(v[e], v[e], pq);
+              }
+              if (NJ != 8 && !on) { ps = 0.0f; pq = 0.0f; }
+              ps = w4_oct_sum(ps);
+              pq = w4_oct_sum(pq);
+              const int64_t slot = (int64_t)(n0 / NT) * 4 + wn * 2 + hn;
+              float *sp_ = a.stats_part + ((mrow + q * 16 + it * 8) * (4 * a.tiles_n) + slot) * 2;
+              if (c8 == 0) *reinterpret_cast<f32x2 *>(sp_) = (f32x2){ps, pq};
+              W4_SB();   // one row at a time: registers (no spills)
+            }
           }
         if (RING) W4_SB();   // the slab's four stores are issued before the next slab's loads
       });
@@ -693,6 +724,11 @@ static void launch_w4_other(const DenseW4Args &a, int nt_width, int fold, hipStr
   }
 }
 
+int64_t fold_stat_slots(int64_t M, int64_t N) {
+  const int width = w4_tile_width(M, N, w4_cu_count() & ~7, dense_rows_dev() != nullptr);
+  return 4 * (N / width);
+}
+
 bool mfma_bf16_dense_w4_fold_supported(const DenseFold &f, int act, int combine,
                                        const void *other, int64_t N) {
   if (f.mode == 1)
@@ -700,6 +736,7 @@ bool mfma_bf16_dense_w4_fold_supported(const DenseFold &f, int act, int combine,
            (uintptr_t)f.rstats % 8 == 0;
   if (f.mode == 2)   // (N <= 2048: the fp32 bias + beta / gamma images share the 16 KiB bias region)
     return N <= 2048 && other && combine == GNLP_COMBINE_ADD && act == GNLP_ACT_IDENTITY && f.rstats &&
+           f.stats_part && (uintptr_t)f.stats_part % 8 == 0 &&
            f.ln_g && f.ln_b && ((uintptr_t)f.ln_g | (uintptr_t)f.ln_b) % 16 == 0 &&
            (uintptr_t)f.rstats % 8 == 0;
   return f.mode == 0;
@@ -722,6 +759,7 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   a.fold_b = mode == 1 ? fold->b : nullptr;
   a.ln_g = mode == 2 ? (const bf16 *)fold->ln_g : nullptr;
   a.ln_b = mode == 2 ? (const bf16 *)fold->ln_b : nullptr;
+  a.stats_part = mode == 2 ? fold->stats_part : nullptr;
   const int width = w4_tile_width(M, N, w4_cu_count() & ~7, a.rows_dev != nullptr);
   a.tiles_n = (int)(N / width);
   a.group_m = knobs().group_m;

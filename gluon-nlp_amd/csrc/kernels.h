@@ -108,6 +108,8 @@ void launch_norm(void *out, const void *x, const void *residual, const void *gam
 bool row_stats_supported(int64_t C, const void *x);
 void launch_row_stats(float *rstats, const void *x, float eps, int64_t rows, int64_t C,
                       hipStream_t s);
+void launch_stats_finish(float *rstats, const float *part, int64_t slots, float eps, int64_t rows,
+                         int64_t C, hipStream_t s);
 void launch_fold_norm_dense(void *wf, float *c, float *bfold, const void *w, const void *b,
                             const void *gamma, const void *beta, int64_t N, int64_t K,
                             int64_t n_scaled, float scale, hipStream_t s);
@@ -153,7 +155,11 @@ struct DenseFold {
   const float *rstats;   // (rows, 2) fp32: r, r * mu of the rows of x (mode 1) / of `other` (mode 2)
   const float *c, *b;    // mode 1: (N) fp32
   const void *ln_g, *ln_b;   // mode 2: (N) bf16
+  float *stats_part;     // mode 2, out: (rows, fold_stat_slots(N), 2) fp32 partial (sum, sum of
+                         // squares) of the OUTPUT rows -- launch_stats_finish turns them into the
+                         // next norm's rstats
 };
+int64_t fold_stat_slots(int64_t M, int64_t N);   // gemm_bf16_w4.hip: 4 per tile column
 bool mfma_bf16_dense_w4_fold_supported(const DenseFold &f, int act, int combine, const void *other,
                                        int64_t N);
 // One-wave-per-SIMD form (gemm_bf16_w4.hip): PERSISTENT, 4 waves of 128x128; M a multiple of 256,

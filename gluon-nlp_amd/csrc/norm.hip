@@ -247,6 +247,35 @@ row_stats_kernel(float *__restrict__ rstats, const bf16 *__restrict__ x, float e
   if (lane == 0) *reinterpret_cast<f32x2 *>(rstats + row * 2) = (f32x2){rstd, rstd * mean};
 }
 
+// The same statistics from the partial sums the producing GEMM's drain left (FOLD 2 of
+// gemm_bf16_w4.hip): (sum, sum of squares) per row and 64-column group, added in slot order.
+// var = E[x^2] - mean^2 in fp32 (relative error ~1e-7 E[x^2] / var: 1e-5 at |mean| = 10 sigma).
+__global__ void __launch_bounds__(256)
+stats_finish_kernel(float *__restrict__ rstats, const float *__restrict__ part, int slots,
+                    float eps, int64_t rows, float inv_c, const int32_t *__restrict__ rows_dev) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  if (rows_dev && row >= *rows_dev) return;
+  const f32x2 *p = reinterpret_cast<const f32x2 *>(part) + row * slots;
+  float s = 0.0f, q = 0.0f;
+  for (int i = 0; i < slots; ++i) {
+    const f32x2 v = p[i];
+    s += v[0];
+    q += v[1];
+  }
+  const float mean = s * inv_c;
+  const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  *reinterpret_cast<f32x2 *>(rstats + row * 2) = (f32x2){rstd, rstd * mean};
+}
+
+void launch_stats_finish(float *rstats, const float *part, int64_t slots, float eps, int64_t rows,
+                         int64_t C, hipStream_t s) {
+  if (rows == 0) return;
+  stats_finish_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(
+      rstats, part, (int)slots, eps, rows, 1.0f / (float)C, dense_rows_dev());
+}
+
 bool row_stats_supported(int64_t C, const void *x) {
   return C % 8 == 0 && C <= 2048 && (uintptr_t)x % 16 == 0;
 }

@@ -39,6 +39,12 @@ for (M, N, K, act, other) in [(32768, 1024, 4096, 'identity', True), (32768, 409
     print('  in-kernel clock (d memtime / d memrealtime x 100 MHz): median %.3f GHz, p10 %.3f, p90 %.3f; '
           'kernel %.1f us' % (np.median(clk), np.percentile(clk, 10), np.percentile(clk, 90),
                               np.median(a[..., 11]) / 100.0))
+    tiles = (M // 256) * (N // 256) / 256.0      # tiles per workgroup (256 workgroups)
+    tot = np.median(a[..., 10])
+    rest = tot - np.median(n) * med.sum()
+    print('  whole kernel %.0f cycles per wave; %d steady K-tiles x %.0f = %.0f; the rest, %.0f cycles = '
+          '%.0f per tile (%.1f tiles per workgroup): first K-tile (~%.0f) + drain + fill' %
+          (tot, int(np.median(n)), med.sum(), np.median(n) * med.sum(), rest, rest / tiles, tiles, med.sum()))
     bw = per.mean(0)   # per wave index
     print('  per wave (mean over workgroups):')
     for w in range(4):
