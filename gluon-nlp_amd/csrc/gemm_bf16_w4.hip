@@ -320,51 +320,71 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   auto gload_f4 = [&](f32x4 &dst, const float *p) __attribute__((always_inline)) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
   };
-  auto gload_f2 = [&](f32x2 &dst, const float *p) __attribute__((always_inline)) {
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
-  };
-  constexpr bool RING = HAS_OTHER || FOLD != 0;
-  constexpr int NL = (HAS_OTHER ? 4 : 0) + (FOLD != 0 ? 4 : 0);   // operations of one L group
+  constexpr bool RING = HAS_OTHER;
+  constexpr int NL = 4;   // operations of one L group
   constexpr int RD = FOLD == 2 ? 2 : 3;   // ring depth (FOLD 2 holds both rings: registers)
   constexpr int NST = FOLD == 2 ? 8 : 4;  // stores of one S group (FOLD 2: + the rows' statistics)
-  auto drain = [&](int m0, int n0) __attribute__((always_inline)) {
+  constexpr int WCOLS = NT / 2;
+  bf16x8 ring[RD][2][2];     // residual / gate rows of RD slabs (HAS_OTHER)
+  f32x2 rst[16];             // FOLD: (r, r mu) of the lane's 16 rows, m0 + 128 wm + (lane >> 3) + 8 j
+  f32x4 fdc[2][2], fdb[2][2];  // FOLD == 1: c, b' of the lane's 8 columns in each 64-column group
+                             // (FOLD == 2: bias + beta and gamma sit in LDS)
+  auto slab_n = [&](int n0, int hn, int c8) -> int64_t {
+    const int nj = NJ - hn * 4 < 4 ? NJ - hn * 4 : 4;
+    const bool on = c8 * 8 < nj * 16;
+    return n0 + wn * WCOLS + hn * 64 + (on ? c8 : 0) * 8;
+  };
+  auto slab_loads = [&](int m0, int n0, int ln, int k) __attribute__((always_inline)) {   // k = hn * 4 + sp
+    const int c8 = ln & 7, rr8 = ln >> 3;
+    const int hn = k >> 2, sp = k & 3;
+    const int64_t n = slab_n(n0, hn, c8);
+    const int64_t mrow = m0 + wm * 128 + sp * 32 + rr8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        gload(ring[k % RD][q][it], a.other + (mrow + q * 16 + it * 8) * a.ldother + n);
+      }
+  };
+  // The statistics of the lane's 16 rows and (FOLD 1) the per-column vectors c, b': loaded BEFORE
+  // the tile's last K-tile, whose own vmcnt wait -- for requests that are younger -- sees them
+  // land: the drain starts on data that is there, and its counted waits see only the residual ring.
+  auto fold_head = [&](int m0, int n0) __attribute__((always_inline)) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const int c8 = ln & 7, rr8 = ln >> 3;   // (of the slab loads; the groups below derive their own)
-    constexpr int WCOLS = NT / 2;
-    bf16x8 ring[RD][2][2];     // residual / gate rows of RD slabs (HAS_OTHER)
-    f32x2 ringst[RD][2][2];    // (r, r mu) of the same rows (FOLD)
-    auto slab_n = [&](int hn) -> int64_t {
-      const int nj = NJ - hn * 4 < 4 ? NJ - hn * 4 : 4;
-      const bool on = c8 * 8 < nj * 16;
-      return n0 + wn * WCOLS + hn * 64 + (on ? c8 : 0) * 8;
-    };
-    // per-column vectors of the lane's 8 columns in each 64-column group: the oldest loads of the
-    // drain, every later counted wait covers them
-    f32x4 fc[2][2], fb[2][2];   // FOLD == 1: c, b'   (FOLD == 2: bias + beta and gamma sit in LDS)
     if constexpr (FOLD == 1) {
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          gload_f4(fc[hn][h], a.fold_c + slab_n(hn) + h * 4);
-          gload_f4(fb[hn][h], a.fold_b + slab_n(hn) + h * 4);
+          gload_f4(fdc[hn][h], a.fold_c + slab_n(n0, hn, ln & 7) + h * 4);
+          gload_f4(fdb[hn][h], a.fold_b + slab_n(n0, hn, ln & 7) + h * 4);
         }
     }
-    auto slab_loads = [&](int k) __attribute__((always_inline)) {   // k = hn * 4 + sp
-      const int hn = k >> 2, sp = k & 3;
-      const int64_t n = slab_n(hn);
-      const int64_t mrow = m0 + wm * 128 + sp * 32 + rr8;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          if constexpr (HAS_OTHER)
-            gload(ring[k % RD][q][it], a.other + (mrow + q * 16 + it * 8) * a.ldother + n);
-          if constexpr (FOLD != 0)
-            gload_f2(ringst[k % RD][q][it], a.rstats + (mrow + q * 16 + it * 8) * 2);
-        }
-    };
+    const float *rp = a.rstats + ((int64_t)m0 + wm * 128 + (ln >> 3)) * 2;
+    // (one address, 16 immediate offsets; written out: asm operands cannot name captures of a
+    // nested lambda)
+#define W4_RST_LD(j)                                            \
+  asm volatile("global_load_dwordx2 %0, %1, off offset:%2"      \
+               : "=&v"(rst[j])                                  \
+               : "v"(rp), "n"((j) * 64)                         \
+               : "memory")
+    W4_RST_LD(0); W4_RST_LD(1); W4_RST_LD(2); W4_RST_LD(3); W4_RST_LD(4); W4_RST_LD(5);
+    W4_RST_LD(6); W4_RST_LD(7); W4_RST_LD(8); W4_RST_LD(9); W4_RST_LD(10); W4_RST_LD(11);
+    W4_RST_LD(12); W4_RST_LD(13); W4_RST_LD(14); W4_RST_LD(15);
+#undef W4_RST_LD
+  };
+  auto drain_head = [&](int m0, int n0) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    if (RING) {
+      slab_loads(m0, n0, ln, 0);
+      if (RD == 3) slab_loads(m0, n0, ln, 1);
+    }
+  };
+  auto drain = [&](int m0, int n0) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     // wait for the loads of slab k: the operations younger than L(k) may stay in flight
     auto slab_wait = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
@@ -374,28 +394,12 @@ dense_bf16_w4_kernel(DenseW4Args a) {
                                      : k <= 5 ? 2 * NL + 2 * NST : k == 6 ? NL + 2 * NST : 2 * NST)
                                   : (k + 1 < 8 ? NL : 0) + (k >= 1 ? NST : 0);
       bf16x8(&r)[2][2] = ring[k % RD];
-      f32x2(&t)[2][2] = ringst[k % RD];
-      if constexpr (HAS_OTHER && FOLD != 0)
-        asm volatile("s_waitcnt vmcnt(%8)"
-                     : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(t[0][0]),
-                       "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1])
-                     : "n"(FLY)
-                     : "memory");
-      else if constexpr (HAS_OTHER)
-        asm volatile("s_waitcnt vmcnt(%4)"
-                     : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])
-                     : "n"(FLY)
-                     : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%4)"
-                     : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1])
-                     : "n"(FLY)
-                     : "memory");
+      asm volatile("s_waitcnt vmcnt(%4)"
+                   : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])
+                   : "n"(FLY)
+                   : "memory");
     };
-    if (RING) {
-      slab_loads(0);
-      if (RD == 3) slab_loads(1);
-    }
+    drain_head(m0, n0);
     w4_static_for<2>([&](auto hnc) __attribute__((always_inline)) {   // 64-column groups of the wave's 128 (96: 64 + 32) columns
       constexpr int hn = decltype(hnc)::value;
       if constexpr (FOLD == 2) {   // (lane-derived addresses are recomputed per group instead of
@@ -423,7 +427,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
         constexpr int k = hn * 4 + sp;
         const int64_t mrow = m0 + wm * 128 + sp * 32 + rr8;
         if constexpr (RING) {   // (lanes that are not `on` re-read column group 0: in bounds, unused)
-          if constexpr (k + RD - 1 < 8) slab_loads(k + RD - 1);
+          if constexpr (k + RD - 1 < 8) slab_loads(m0, n0, ln, k + RD - 1);
           slab_wait(std::integral_constant<int, k>{});
         }
         f32x4 lo[2][2], hi[2][2];
@@ -455,14 +459,14 @@ dense_bf16_w4_kernel(DenseW4Args a) {
             // vector-ALU instructions per tile)
             f32x2 g[4];   // columns 0 1 | 2 3 | 4 5 | 6 7
             if constexpr (FOLD == 1) {   // r * acc + (b' - (r mu) c)
-              const f32x2 st = ringst[k % RD][q][it];
+              const f32x2 st = rst[sp * 4 + q * 2 + it];
               const f32x2 r2 = {st[0], st[0]}, nm2 = {-st[1], -st[1]};
 #pragma unroll
               for (int e = 0; e < 4; e += 2) {
-                const f32x2 t0 = (f32x2){fc[hn][0][e], fc[hn][0][e + 1]} * nm2 +
-                                 (f32x2){fb[hn][0][e], fb[hn][0][e + 1]};
-                const f32x2 t1 = (f32x2){fc[hn][1][e], fc[hn][1][e + 1]} * nm2 +
-                                 (f32x2){fb[hn][1][e], fb[hn][1][e + 1]};
+                const f32x2 t0 = (f32x2){fdc[hn][0][e], fdc[hn][0][e + 1]} * nm2 +
+                                 (f32x2){fdb[hn][0][e], fdb[hn][0][e + 1]};
+                const f32x2 t1 = (f32x2){fdc[hn][1][e], fdc[hn][1][e + 1]} * nm2 +
+                                 (f32x2){fdb[hn][1][e], fdb[hn][1][e + 1]};
                 g[e >> 1] = (f32x2){lo[q][it][e], lo[q][it][e + 1]} * r2 + t0;
                 g[2 + (e >> 1)] = (f32x2){hi[q][it][e], hi[q][it][e + 1]} * r2 + t1;
               }
@@ -488,7 +492,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
               if constexpr (FOLD == 2) {   // + gamma * (r s - r mu)   (beta sits in the bias image)
                 // (gamma is re-read from LDS row by row: held in 8 registers this instantiation
                 // spills, and spill traffic would sit in the counted vmcnt queue)
-                const f32x2 st = ringst[k % RD][q][it];
+                const f32x2 st = rst[sp * 4 + q * 2 + it];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                   const f32x4 g4 =
@@ -623,6 +627,9 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     advance();
     par ^= 1;
     for (int t = 1; t < nk; ++t) {
+      if constexpr (FOLD != 0) {
+        if (t == nk - 1) fold_head(m0, n0);
+      }
       ktile(std::false_type{}, smem + par * BUF, smem + (par ^ 1) * BUF, pA, pB);
       advance();
       par ^= 1;
