@@ -254,7 +254,11 @@ def test_one_wave_per_simd_gemm_static_checks(tmp_path):
                 run = []
             else:
                 run.append(l)
-    assert bodies == 2 * len(names)   # the tile's first K-tile (C = 0) and the loop body
+    # the tile's first K-tile (C = 0) and the loop body; the instantiations with a folded LayerNorm
+    # branch to their statistics loads ahead of the last K-tile and the compiler may peel that
+    # K-tile into a third body (every body found has passed the checks above)
+    n_fold = sum(re.search(r'ELi[12]EEEvNS_11DenseW4ArgsE$', n) is not None for n in names)
+    assert n_fold == 10 and 2 * len(names) <= bodies <= 2 * len(names) + n_fold, bodies
     # the residual ring's inline-asm global loads: no register they write is named before a vmcnt
     # wait (the compiler believes an asm output is valid at once)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_async_regs.py'), asm],
