@@ -751,6 +751,30 @@ int gnlp_activation(void *out, const void *x, int dtype, int64_t n, int act, gnl
   return check_launch("gnlp_activation");
 }
 
+int gnlp_dense_epilogue(void *y, const void *z, const void *other, int dtype, int64_t n, int act,
+                        int combine, gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(act >= GNLP_ACT_IDENTITY && act <= GNLP_ACT_SOFTSIGN, "act=%d is not supported", act);
+  REQUIRE(combine == GNLP_COMBINE_ADD || combine == GNLP_COMBINE_MUL, "bad combine %d", combine);
+  REQUIRE(n >= 0 && ((y && z) || n == 0), "bad tensor");
+  launch_dense_epilogue(y, z, other, dtype, n, act, combine == GNLP_COMBINE_MUL, S(stream));
+  return check_launch("gnlp_dense_epilogue");
+}
+
+int gnlp_dense_epilogue_backward(void *dz, void *d_other, const void *g, const void *z,
+                                 const void *other, int dtype, int64_t n, int act, int combine,
+                                 gnlp_stream_t stream) {
+  REQUIRE(dtype_ok(dtype), "unsupported dtype %d", dtype);
+  REQUIRE(act >= GNLP_ACT_IDENTITY && act <= GNLP_ACT_SOFTSIGN, "act=%d is not supported", act);
+  REQUIRE(combine == GNLP_COMBINE_ADD || combine == GNLP_COMBINE_MUL, "bad combine %d", combine);
+  REQUIRE(n >= 0 && ((dz && g && z) || n == 0), "bad tensor");
+  const bool mul = combine == GNLP_COMBINE_MUL;
+  REQUIRE(!mul || other, "combine mul needs `other`");
+  REQUIRE(!d_other || mul, "d_other is only written for combine mul (for add it equals g)");
+  launch_dense_epilogue_bwd(dz, d_other, g, z, mul ? other : nullptr, dtype, n, act, mul, S(stream));
+  return check_launch("gnlp_dense_epilogue_backward");
+}
+
 int gnlp_norm(void *out, const void *x, const void *residual, const void *gamma, const void *beta,
               int dtype, int kind, float eps, int64_t rows, int64_t C, const void *valid_length,
               int vl_dtype, int64_t B, int64_t L, int time_major, gnlp_stream_t stream) {

@@ -161,4 +161,42 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   }
 }
 
+// d act(x) / dx of the activations above, with the exact formulas (the backward of the fused Dense
+// epilogues and of get_activation; layers.py:236-338 under autograd)
+__device__ __forceinline__ float apply_dact(float x, int act) {
+  switch (act) {
+    case GNLP_ACT_IDENTITY: return 1.0f;
+    case GNLP_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    case GNLP_ACT_GELU_ERF: {
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    }
+    case GNLP_ACT_GELU_TANH: {
+      const float k = 0.79788456080286535588f;
+      const float t = tanhf(k * (x + 0.044715f * x * x * x));
+      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x * x);
+    }
+    case GNLP_ACT_GELU_SIGMOID: {
+      const float s = 1.0f / (1.0f + expf(-1.702f * x));
+      return s + 1.702f * x * s * (1.0f - s);
+    }
+    case GNLP_ACT_SIGMOID: {
+      const float s = 1.0f / (1.0f + expf(-x));
+      return s * (1.0f - s);
+    }
+    case GNLP_ACT_TANH: {
+      const float t = tanhf(x);
+      return 1.0f - t * t;
+    }
+    case GNLP_ACT_LEAKY: return x > 0.0f ? 1.0f : 0.1f;
+    case GNLP_ACT_ELU: return x > 0.0f ? 1.0f : expf(x);
+    case GNLP_ACT_SOFTRELU: return 1.0f / (1.0f + expf(-x));
+    case GNLP_ACT_SOFTSIGN: {
+      const float d = 1.0f + fabsf(x);
+      return 1.0f / (d * d);
+    }
+    default: return 1.0f;
+  }
+}
+
 }  // namespace gnlp

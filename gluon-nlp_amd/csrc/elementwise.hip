@@ -308,6 +308,59 @@ static void act_t(void *out, const void *x, int64_t n, int act, hipStream_t s) {
   }
 }
 
+// The epilogue of Dense as an operation of its own, and its backward (training: the fused GEMM
+// epilogues keep no pre-activation; under autograd Dense saves z = x W^T + b and applies these).
+//   forward:   y = combine(act(z), other)
+//   backward:  dz = g act'(z) [* other],   d_other = g act(z)   (combine mul; for add d_other = g)
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256)
+dense_epilogue_kernel(T *__restrict__ o0, T *__restrict__ o1, const T *__restrict__ g,
+                      const T *__restrict__ z, const T *__restrict__ other, int64_t n, int act,
+                      int mul) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float zv = to_f32(z[i]);
+  const float ov = other ? to_f32(other[i]) : 0.0f;
+  if (!BWD) {
+    const float a = apply_act<true>(zv, act);
+    o0[i] = from_f32<T>(other ? (mul ? a * ov : a + ov) : a);
+  } else {
+    const float gv = to_f32(g[i]);
+    const float d = apply_dact(zv, act);
+    o0[i] = from_f32<T>(mul ? gv * ov * d : gv * d);
+    if (o1) o1[i] = from_f32<T>(gv * apply_act<true>(zv, act));
+  }
+}
+
+void launch_dense_epilogue(void *y, const void *z, const void *other, int dtype, int64_t n, int act,
+                           int mul, hipStream_t s) {
+  if (n == 0) return;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (dtype == GNLP_BF16)
+    dense_epilogue_kernel<bf16, false><<<grid, 256, 0, s>>>((bf16 *)y, nullptr, nullptr,
+                                                            (const bf16 *)z, (const bf16 *)other, n,
+                                                            act, mul);
+  else
+    dense_epilogue_kernel<float, false><<<grid, 256, 0, s>>>((float *)y, nullptr, nullptr,
+                                                             (const float *)z, (const float *)other,
+                                                             n, act, mul);
+}
+
+void launch_dense_epilogue_bwd(void *dz, void *d_other, const void *g, const void *z,
+                               const void *other, int dtype, int64_t n, int act, int mul,
+                               hipStream_t s) {
+  if (n == 0) return;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (dtype == GNLP_BF16)
+    dense_epilogue_kernel<bf16, true><<<grid, 256, 0, s>>>((bf16 *)dz, (bf16 *)d_other,
+                                                           (const bf16 *)g, (const bf16 *)z,
+                                                           (const bf16 *)other, n, act, mul);
+  else
+    dense_epilogue_kernel<float, true><<<grid, 256, 0, s>>>((float *)dz, (float *)d_other,
+                                                            (const float *)g, (const float *)z,
+                                                            (const float *)other, n, act, mul);
+}
+
 void launch_activation(void *out, const void *x, int dtype, int64_t n, int act, hipStream_t s) {
   if (dtype == GNLP_BF16) act_t<bf16>(out, x, n, act, s);
   else act_t<float>(out, x, n, act, s);

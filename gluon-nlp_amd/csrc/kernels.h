@@ -80,6 +80,11 @@ void launch_mem_mask(uint8_t *mask, const void *mem_vl, const void *data_vl, int
 void launch_sequence_mask(void *out, const void *x, const void *vl, int vl_dtype, int dtype,
                           int64_t B, int64_t L, int64_t C, int time_major, hipStream_t s);
 void launch_activation(void *out, const void *x, int dtype, int64_t n, int act, hipStream_t s);
+void launch_dense_epilogue(void *y, const void *z, const void *other, int dtype, int64_t n, int act,
+                           int mul, hipStream_t s);
+void launch_dense_epilogue_bwd(void *dz, void *d_other, const void *g, const void *z,
+                               const void *other, int dtype, int64_t n, int act, int mul,
+                               hipStream_t s);
 void launch_l2_normalize(void *out, const void *x, int dtype, int64_t rows, int64_t d, float eps,
                          hipStream_t s);
 void launch_rel_position(int32_t *out, int64_t L, hipStream_t s);

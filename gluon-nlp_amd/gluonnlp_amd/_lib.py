@@ -103,6 +103,10 @@ PROTOTYPES = {
                                        c_void_p, c_void_p, c_void_p, c_int, c_float, c_int64,
                                        c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
                                        c_void_p]),
+    'gnlp_dense_epilogue': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
+                                    c_void_p]),
+    'gnlp_dense_epilogue_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_int64, c_int, c_int, c_void_p]),
     'gnlp_dense': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     'gnlp_attn_workspace_bytes': (c_size_t, [POINTER(AttnDesc), c_int, c_int, c_int]),

@@ -182,31 +182,114 @@ class DenseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         x, w = ctx.saved_tensors
-        dev = x.device
+        N, K = w.shape
+        dx, dw, db = _dense_grads(ctx.needs_input_grad, g_out.contiguous().reshape(-1, N),
+                                  x.contiguous().reshape(-1, K), w, ctx.bias_dtype, x.device)
+        if dx is not None:
+            dx = dx.reshape(x.shape)
+        return dx, dw, db, None
+
+
+def _dense_grads(ctx_needs, g2, x2, w, bias_dtype, dev):
+    """dx = g W, dW = g^T x (gnlp_dense on transposed operands; the transposes are torch copies:
+    plumbing), db = column sums of g (gnlp_colsum) for y = x W^T + b with g = dL/dy."""
+    lib = _lib.load()
+    N, K = w.shape
+    M = x2.shape[0]
+
+    def mm(a, bt):     # a (m, k) @ bt (n, k)^T -> (m, n) through gnlp_dense
+        m, k = a.shape
+        n = bt.shape[0]
+        out = torch.empty((m, n), dtype=a.dtype, device=dev)
+        _lib.check(lib.gnlp_dense(T.ptr(out), T.ptr(a), T.ptr(bt), None, None,
+                                  _lib.COMBINE_ADD, _lib.ACT['identity'], T.code(a), m, n, k,
+                                  k, n, n, T.stream(dev)))
+        return out
+    dx = dw = db = None
+    if ctx_needs[0]:
+        dx = mm(g2, w.detach().t().contiguous())
+    if ctx_needs[1]:
+        dw = mm(g2.t().contiguous(), x2.t().contiguous())
+    if bias_dtype is not None and ctx_needs[2]:
+        acc = torch.empty((N,), dtype=torch.float32, device=dev)
+        _lib.check(lib.gnlp_colsum(T.ptr(acc), T.ptr(g2), T.code(g2), M, N, T.stream(dev)))
+        db = _cast_from_f32(acc, bias_dtype, dev)
+    return dx, dw, db
+
+
+class DenseEpilogueFn(torch.autograd.Function):
+    """``Dense`` with its fused epilogue under autograd: y = combine(act(x W^T + b), other)
+    (layers.py:640-642, models/transformer.py:266-268 differentiated op by op by mx.autograd).
+    The fused GEMM epilogues keep no pre-activation, so the recording forward runs the plain GEMM,
+    saves z = x W^T + b and applies the epilogue as an elementwise kernel (gnlp_dense_epilogue);
+    the backward is gnlp_dense_epilogue_backward (dz, and d_other of a gate) followed by the plain
+    Dense gradients.  For combine 'add' d_other is the cotangent itself."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, other, act, combine, call_plain):
+        z = call_plain(x, weight, bias)
+        dev = z.device
+        y = torch.empty_like(z)
+        _lib.check(_lib.load().gnlp_dense_epilogue(
+            T.ptr(y), T.ptr(z), T.ptr(other), T.code(z), z.numel(), act, combine, T.stream(dev)))
+        ctx.save_for_backward(x, weight, z, other)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        ctx.act, ctx.combine = act, combine
+        return y
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, w, z, other = ctx.saved_tensors
+        dev = z.device
         lib = _lib.load()
         N, K = w.shape
-        g2 = g_out.contiguous().reshape(-1, N)
-        x2 = x.contiguous().reshape(-1, K)
-        M = x2.shape[0]
+        g = g_out.contiguous()
+        mul = ctx.combine == _lib.COMBINE_MUL
+        dz = torch.empty_like(z)
+        d_other = None
+        if other is not None and ctx.needs_input_grad[3]:
+            d_other = torch.empty_like(z) if mul else g
+        _lib.check(lib.gnlp_dense_epilogue_backward(
+            T.ptr(dz), T.ptr(d_other) if mul else None, T.ptr(g), T.ptr(z),
+            T.ptr(other) if mul else None, T.code(z), z.numel(), ctx.act, ctx.combine,
+            T.stream(dev)))
+        dx, dw, db = _dense_grads(ctx.needs_input_grad, dz.reshape(-1, N),
+                                  x.contiguous().reshape(-1, K), w, ctx.bias_dtype, dev)
+        if dx is not None:
+            dx = dx.reshape(x.shape)
+        return dx, dw, db, d_other, None, None, None
 
-        def mm(a, bt):     # a (m, k) @ bt (n, k)^T -> (m, n) through gnlp_dense
-            m, k = a.shape
-            n = bt.shape[0]
-            out = torch.empty((m, n), dtype=a.dtype, device=dev)
-            _lib.check(lib.gnlp_dense(T.ptr(out), T.ptr(a), T.ptr(bt), None, None,
-                                      _lib.COMBINE_ADD, _lib.ACT['identity'], T.code(a), m, n, k,
-                                      k, n, n, T.stream(dev)))
-            return out
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = mm(g2, w.detach().t().contiguous()).reshape(x.shape)
-        if ctx.needs_input_grad[1]:
-            dw = mm(g2.t().contiguous(), x2.t().contiguous())
-        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
-            acc = torch.empty((N,), dtype=torch.float32, device=dev)
-            _lib.check(lib.gnlp_colsum(T.ptr(acc), T.ptr(g2), T.code(g2), M, N, T.stream(dev)))
-            db = _cast_from_f32(acc, ctx.bias_dtype, dev)
-        return dx, dw, db, None
+
+class ActFn(torch.autograd.Function):
+    """get_activation(...) as a module of its own (layers.py:236-338) under autograd."""
+
+    @staticmethod
+    def forward(ctx, x, act, call):
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return call(x)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().gnlp_dense_epilogue_backward(
+            T.ptr(dx), None, T.ptr(g_out.contiguous()), T.ptr(x), None, T.code(x), x.numel(),
+            ctx.act, _lib.COMBINE_ADD, T.stream(x.device)))
+        return dx, None, None
+
+
+class SeqMaskFn(torch.autograd.Function):
+    """npx.sequence_mask (models/bert.py:311-312) under autograd: the cotangent is masked alike."""
+
+    @staticmethod
+    def forward(ctx, x, call):
+        ctx.call = call
+        return call(x)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        return ctx.call(g_out.contiguous()), None
 
 
 class BucketEmbedFn(torch.autograd.Function):

@@ -12,7 +12,7 @@ from torch import nn
 
 from . import _lib
 from . import _tensor as T
-from .autograd import BucketEmbedFn, DenseFn, NormFn, wants_grad
+from .autograd import ActFn, BucketEmbedFn, DenseEpilogueFn, DenseFn, NormFn, wants_grad
 
 __all__ = ['PositionwiseFFN', 'GELU', 'get_activation', 'get_norm_layer', 'RMSNorm', 'NoNorm',
            'LayerNorm', 'Dense', 'BucketPositionalEmbedding', 'IdentityActivation', 'Activation',
@@ -20,9 +20,8 @@ __all__ = ['PositionwiseFFN', 'GELU', 'get_activation', 'get_norm_layer', 'RMSNo
 
 
 def _empty_param(shape, dtype):
-    # inference is the path: parameters are created frozen.  The norm layers' gamma / beta take a
-    # gradient once the caller flips ``requires_grad_(True)`` (autograd.NormFn); Dense has no
-    # backward kernel yet.
+    # inference is the path: parameters are created frozen; every layer records its backward once
+    # the caller flips ``requires_grad_(True)`` (autograd.py).
     return nn.Parameter(torch.zeros(shape, dtype=T.torch_dtype(dtype)), requires_grad=False)
 
 
@@ -54,9 +53,13 @@ class Activation(nn.Module):
         xt = T.as_tensor(x)
         dev = T.require_device(xt)
         xt = xt.contiguous()
-        out = torch.empty_like(xt)
-        _lib.check(_lib.load().gnlp_activation(T.ptr(out), T.ptr(xt), T.code(xt), xt.numel(),
-                                               _lib.ACT[self._act], T.stream(dev)))
+
+        def call(xt):
+            out = torch.empty_like(xt)
+            _lib.check(_lib.load().gnlp_activation(T.ptr(out), T.ptr(xt), T.code(xt), xt.numel(),
+                                                   _lib.ACT[self._act], T.stream(dev)))
+            return out
+        out = ActFn.apply(xt, _lib.ACT[self._act], call) if wants_grad(xt) else call(xt)
         return T.like_caller(out, x)
 
     def __repr__(self):
@@ -289,12 +292,26 @@ class Dense(nn.Module):
             return out
 
         if wants_grad(xt, ot, w, b):
-            # training through the plain layer only: y = x W^T + b (autograd.DenseFn)
-            if ot is not None or act != 'identity' or out is not None:
-                raise NotImplementedError(
-                    'the backward pass of the fused Dense epilogues (activation / other / out=) '
-                    'is not built; differentiate the plain layer or run under torch.no_grad()')
-            res = DenseFn.apply(xt, w, b, call)
+            if out is not None:
+                raise ValueError('Dense(out=...) writes into a caller buffer and cannot be '
+                                 'recorded by autograd; drop out= or run under torch.no_grad()')
+            if ot is None and act == 'identity':   # y = x W^T + b
+                res = DenseFn.apply(xt, w, b, call)
+            else:   # the fused epilogue, differentiated through the saved pre-activation
+                def call_plain(xt, w, b):
+                    xt = xt.contiguous()
+                    M = xt.numel() // max(K, 1)
+                    z = torch.empty(xt.shape[:-1] + (N,), dtype=xt.dtype, device=dev)
+                    _lib.check(_lib.load().gnlp_dense(
+                        T.ptr(z), T.ptr(xt), T.ptr(w), T.ptr(b), None, _lib.COMBINE_ADD,
+                        _lib.ACT['identity'], T.code(xt), M, N, K, K, N, N, T.stream(dev)))
+                    return z
+                if ot is not None and tuple(ot.shape) != tuple(xt.shape[:-1]) + (N,):
+                    raise ValueError('other {} does not match the output {}'.format(
+                        tuple(ot.shape), tuple(xt.shape[:-1]) + (N,)))
+                res = DenseEpilogueFn.apply(
+                    xt, w, b, ot, _lib.ACT[act],
+                    _lib.COMBINE_MUL if combine == 'mul' else _lib.COMBINE_ADD, call_plain)
         else:
             res = call(xt, w, b)
         return T.like_caller(res, x)
@@ -563,6 +580,8 @@ class PositionwiseFFN(nn.Module):
         kind, _ = _norm_kind(self.layer_norm)
         if self._act_name is None or kind is None:
             return self._forward_unfused(data)
+        if wants_grad(T.as_tensor(data), *self.parameters()):
+            return self._forward_unfused(data)   # op by op: every op records its backward
         x = T.as_tensor(data)
         dev = T.require_device(x, self.ffn_1.weight.data)
         x = x.contiguous()

@@ -12,6 +12,7 @@ from .. import _lib
 from .. import _tensor as T
 from ..attention_cell import (MultiHeadAttentionCell, gen_mem_attn_mask, gen_self_attn_mask,
                               mask_predicate)
+from ..autograd import SeqMaskFn, wants_grad
 from ..layers import Dense, LayerNorm, PositionwiseFFN, ffn_params_struct, memory_kv
 
 __all__ = ['TransformerEncoderLayer', 'TransformerEncoder', 'run_encoder_stack',
@@ -94,6 +95,9 @@ class TransformerEncoderLayer(nn.Module):
         ``output_attention`` is off) returns ``None`` for attn_weight and lets the fused
         attention kernel run."""
         x = T.as_tensor(data)
+        if wants_grad(x, *self.parameters()):
+            return self._forward_recorded(data, attn_mask, _need_weights, _valid_length,
+                                          _final_seq_mask)
         m = T.as_tensor(attn_mask)
         vlt, vlp, vlc = T.valid_length_arg(_valid_length)
         dev = T.require_device(x, m, vlt, self.attn_qkv.weight.data)
@@ -129,6 +133,29 @@ class TransformerEncoderLayer(nn.Module):
             T.ptr(w), int(bool(_final_seq_mask)), T.ptr(ws), 0 if ws is None else ws.numel(),
             T.stream(dev)))
         return T.like_caller(out, data), (T.like_caller(w, data) if w is not None else None)
+
+    def _forward_recorded(self, data, attn_mask, need_weights, valid_length, final_seq_mask):
+        """The same layer op by op, every op recording its backward (training; the reference
+        differentiates exactly this composition under mx.autograd, models/transformer.py:259-271):
+        Dense (+ residual epilogue), the attention cell, LayerNorm and the FFN are the autograd
+        functions of autograd.py over the HIP kernels."""
+        x = T.as_tensor(data)
+        if self._pre_norm:                      # :259-260 (data is REBOUND to the normalised tensor)
+            x = self.layer_norm(x)
+        U, H = self._units, self._num_heads
+        qkv = self.attn_qkv(x)                  # :261
+        q, k, v = [qkv[..., i * U:(i + 1) * U].reshape(x.shape[0], x.shape[1], H, U // H)
+                   for i in range(3)]           # :262-264
+        ctx, (_, w) = self.attention_cell(q, k, v, attn_mask, None, _need_scores=False,
+                                          _need_weights=need_weights,
+                                          _valid_length=valid_length)          # :265
+        out = self.attention_proj(ctx, other=x, combine='add')                 # :266-268
+        if not self._pre_norm:
+            out = self.layer_norm(out)          # :269-270
+        out = self.ffn(out)                     # :271
+        if final_seq_mask:
+            out = sequence_mask(out, valid_length, self._layout)
+        return T.like_caller(T.as_tensor(out), data), w
 
 
 # ---- LayerNorms folded into the GEMMs around them (bf16 post-norm stacks) ---------------------
@@ -208,10 +235,36 @@ def _folded_params(layers, dev):
     return arr, keep
 
 
+def sequence_mask(data, valid_length, layout):
+    """npx.sequence_mask(data, valid_length, axis=time) (models/bert.py:311-312); records its
+    backward (the cotangent masked alike) under autograd."""
+    x = T.as_tensor(data).contiguous()
+    vlt, vlp, vlc = T.valid_length_arg(valid_length)
+    dev = T.require_device(x, vlt)
+    B, L = (x.shape[0], x.shape[1]) if layout == 'NT' else (x.shape[1], x.shape[0])
+
+    def call(t):
+        out = torch.empty_like(t)
+        _lib.check(_lib.load().gnlp_sequence_mask(T.ptr(out), T.ptr(t), vlp, vlc, T.code(t), B, L,
+                                                  t.shape[-1], int(layout == 'TN'), T.stream(dev)))
+        return out
+    return SeqMaskFn.apply(x, call) if wants_grad(x) else call(x)
+
+
 def run_encoder_stack(layers, data, valid_length, layout, final_seq_mask, all_encodings=False):
     """Run a list of post-/pre-norm TransformerEncoderLayers back to back in ONE C call
     (gnlp_encoder_stack_forward); the mask is the valid_length predicate evaluated in-kernel."""
     x = T.as_tensor(data)
+    if wants_grad(x, *[p for ly in layers for p in ly.parameters()]):
+        # training: layer by layer, every op recording its backward (bert.py:295-312)
+        outs, h = [], data
+        for i, ly in enumerate(layers):
+            seqm = bool(final_seq_mask) and valid_length is not None and \
+                (all_encodings or i == len(layers) - 1)
+            h, _ = ly(h, None, _need_weights=False, _valid_length=valid_length,
+                      _final_seq_mask=seqm)
+            outs.append(h)
+        return outs if all_encodings else h
     vlt, vlp, vlc = T.valid_length_arg(valid_length)
     l0 = layers[0]
     dev = T.require_device(x, vlt, l0.attn_qkv.weight.data)

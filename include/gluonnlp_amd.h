@@ -102,6 +102,21 @@ int gnlp_l2_normalize(void *out, const void *x, int dtype, int64_t rows, int64_t
 /* get_activation(act)(x)   layers.py:236-338 (GELU erf/tanh/sigmoid, relu, ...), n elements. */
 int gnlp_activation(void *out, const void *x, int dtype, int64_t n, int act, gnlp_stream_t stream);
 
+/* The epilogue of Dense as an operation of its own, and its backward (training: mx.autograd
+ * differentiates nn.Dense + get_activation + the residual add op by op, layers.py:633-647,
+ * models/transformer.py:266-268; the fused GEMM epilogues of gnlp_dense keep no pre-activation,
+ * so under autograd the Python layer saves z = x W^T + b and applies these).  n elements, all
+ * tensors contiguous and of `dtype`.
+ *   gnlp_dense_epilogue:           y = combine(act(z), other)            (other may be NULL)
+ *   gnlp_dense_epilogue_backward:  combine add: dz = g act'(z)           (d_other = g: not written)
+ *                                  combine mul: dz = g other act'(z), d_other = g act(z) (or NULL)
+ * act' uses the exact formulas (erff / tanhf / expf). */
+int gnlp_dense_epilogue(void *y, const void *z, const void *other, int dtype, int64_t n, int act,
+                        int combine, gnlp_stream_t stream);
+int gnlp_dense_epilogue_backward(void *dz, void *d_other, const void *g, const void *z,
+                                 const void *other, int dtype, int64_t n, int act, int combine,
+                                 gnlp_stream_t stream);
+
 /* nn.LayerNorm / RMSNorm / NoNorm over the last axis   models/transformer.py:217-218,
  * layers.py:63,81-138,151-181.  y = norm(x [+ residual]) * gamma + beta, statistics in fp32.
  * residual, beta may be NULL.  If valid_length != NULL the rows are interpreted as (B, L)
