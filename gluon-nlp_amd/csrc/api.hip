@@ -219,8 +219,12 @@ int dense_launch(void *out, const void *x, const void *w, const void *bias, cons
 size_t attn_ws_bytes(const gnlp_attn_desc *d, int dtype, bool want_scores, bool want_weights,
                      bool fused) {
   if (fused) return 0;
-  if (d->dk <= 128 && d->dv <= 128 && ((d->Lq + 31) / 32) * d->H * d->B <= 0x7fffffffLL)
-    return 0;   // attn_gen.hip (gen_attn_supported): nothing is materialised
+  {   // attn_gen.hip takes it (the SAME predicate the dispatcher asks): nothing is materialised
+    GenAttn ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.B = d->B; ga.H = d->H; ga.Lq = d->Lq; ga.Lm = d->Lm; ga.dk = d->dk; ga.dv = d->dv;
+    if (gen_attn_supported(ga)) return 0;
+  }
   if (want_scores && want_weights) return 0;
   return align256((size_t)d->B * d->H * d->Lq * d->Lm * esize(dtype));
 }
@@ -514,9 +518,15 @@ constexpr size_t kStaticScratchBytes = GNLP_NOALLOC_SCRATCH_BYTES;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 std::atomic<void *> g_scratch_ptr[64];   // per device ordinal
 
-int static_scratch(void **ptr) {
+int static_scratch(void **ptr, hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail(GNLP_ERR_LAUNCH, "hipGetDevice failed");
+  if (stream) {   // the kernels run on the stream's device: it must be the one whose copy we hand out
+    hipDevice_t sdev = -1;
+    if (hipStreamGetDevice(stream, &sdev) == hipSuccess && (int)sdev != dev)
+      return fail(GNLP_ERR_ARG, "gnlp_encoder_layer_forward_noalloc: the stream belongs to device "
+                  "%d but device %d is current; make the stream's device current", (int)sdev, dev);
+  }
   if (dev < 0 || dev >= 64) return fail(GNLP_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
   void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
   if (!p) {
@@ -856,7 +866,8 @@ int gnlp_multi_head_dot_attn(void *ctx, void *scores_out, void *weights_out, con
           "d->mem_lengths selects the memory-mask predicate: mask NULL, not causal, valid_length "
           "with 2 B entries");
   if (d->B * d->H * d->Lq * d->dv == 0) return GNLP_OK;
-  REQUIRE(ctx && q && k && v, "NULL tensor");
+  // d_k == 0: query and key hold no element (their pointers may be NULL), every score is 0
+  REQUIRE(ctx && v && ((q && k) || d->dk == 0), "NULL tensor");
   return attn_impl(ctx, scores_out, weights_out, q, k, v, d, dtype, mask, mask_stride,
                    valid_length, vl_dtype, edge_scores, edge_stride, temperature, workspace,
                    workspace_bytes, S(stream));
@@ -1234,7 +1245,7 @@ int gnlp_encoder_layer_forward_noalloc(void *out, const void *x,
           "scratch holds %zu (GNLP_NOALLOC_SCRATCH_BYTES); use gnlp_encoder_layer_forward with a "
           "caller-owned workspace", need, kStaticScratchBytes);
   void *ws = nullptr;
-  rc = static_scratch(&ws);   // first call on this device: one hipGetSymbolAddress, no allocation
+  rc = static_scratch(&ws, S(stream));   // first call on this device: one hipGetSymbolAddress, no allocation
   if (rc) return rc;
   // every region of the scratch is written by this call before it is read: nothing to clear
   return encoder_layer_impl(out, x, p, cfg, B, L, mask, valid_length, vl_dtype, attn_weights_out,

@@ -232,7 +232,12 @@ def memory_kv(prev_state, mem, k_dense, v_dense):
     (``prev_state``) when the very same memory tensor object comes in again with its version
     counter, and the four parameters with their storage and version counters, unchanged.  The
     first step, states that went through a reordering (beam search), autograd, non-torch callers
-    (a fresh DLPack view per call) and every mismatch recompute."""
+    (a fresh DLPack view per call) and every mismatch recompute.
+
+    Limit: version counters do not see in-place writes through ``.data`` (``p.data.copy_(...)``,
+    ``mem.data.mul_(...)``); after such an edit of the memory or of the key / value projections,
+    call ``drop_memory_kv(states)`` on the decoding states (or start from fresh states) -- a state
+    that still carries the pair would serve the projections of the old values."""
     m = T.as_tensor(mem)
     params = [p for p in (k_dense.weight, k_dense.bias, v_dense.weight, v_dense.bias)
               if p is not None]
@@ -245,6 +250,21 @@ def memory_kv(prev_state, mem, k_dense, v_dense):
             return hit[2], hit[3], hit
     k, v = T.as_tensor(k_dense(m)), T.as_tensor(v_dense(m))
     return k, v, ((m, key, k, v) if key is not None else None)
+
+
+def drop_memory_kv(states):
+    """Forget the memory key / value projections that travel with incremental-decoding states
+    (any nesting of lists / tuples of the tensors ``incremental_decode`` returned): the next step
+    projects the memory again.  For callers that edited the memory or the projection weights in
+    place through ``.data`` (see ``memory_kv``)."""
+    if isinstance(states, (list, tuple)):
+        for s_ in states:
+            drop_memory_kv(s_)
+    elif hasattr(states, '_gnlp_memory_kv'):
+        try:
+            del states._gnlp_memory_kv
+        except AttributeError:
+            states._gnlp_memory_kv = None
 
 
 class Dense(nn.Module):

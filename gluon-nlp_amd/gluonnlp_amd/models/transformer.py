@@ -558,7 +558,10 @@ class TransformerDecoder(nn.Module):
 
     def incremental_decode(self, data, states, mem, mem_valid_length):
         """data (B, C_in), one cache pair per layer -> (out (B, C_out), new caches).
-        models/transformer.py:884-959: the memory mask (B, 1, mem_length) is built once."""
+        models/transformer.py:884-959: the memory mask (B, 1, mem_length) is built once.
+        The memory's key / value projections are kept in the states between steps
+        (layers.memory_kv): they follow optimizer steps and copy_() of the weights, not writes
+        through ``.data`` -- call layers.drop_memory_kv(states) after those."""
         out = data
         if self._data_norm:
             out = self.ln_data(out)

@@ -438,7 +438,9 @@ int gnlp_encoder_layer_forward(void *out, const void *x, const gnlp_encoder_laye
  * pre-norm sums, FFN hidden) lives in a static device array of GNLP_NOALLOC_SCRATCH_BYTES inside
  * the library -- every GPU the library runs on holds one copy until the process ends.  The call
  * performs no hipMalloc / hipFree and calls no allocating routine; on its first use on a device it
- * looks the array's address up once (hipGetSymbolAddress).  A layer whose scratch
+ * looks the array's address up once (hipGetSymbolAddress): make one warm-up call per device OUTSIDE
+ * any graph capture.  The stream must belong to the CURRENT device (each GPU has its own copy of
+ * the array; a mismatch is refused with GNLP_ERR_ARG).  A layer whose scratch
  * (gnlp_encoder_workspace_bytes minus the stack's two ping-pong activations) exceeds the array is
  * refused with GNLP_ERR_ARG and a message.  Every call on a GPU shares that GPU's array: calls that
  * overlap in time on one GPU (different streams or threads) RACE -- serialise them, or use the

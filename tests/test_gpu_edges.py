@@ -103,3 +103,34 @@ def test_c_abi_argument_errors(nlp):
     assert rc != 0 and b'divisive' in lib.gnlp_last_error()
     with pytest.raises(_lib.GnlpError):
         _lib.check(rc)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_attention_with_zero_key_units(nlp, dtype):
+    """query / key of width 0 (the reference's batch_dot over an empty axis: all scores 0): the
+    general MFMA kernel declines (d_k < 1), the unfused path must size its scores workspace itself
+    (the workspace query used to answer 0 for it: a NULL scores buffer) -- uniform weights over the
+    unmasked keys, context = their mean of V, masked rows exact zeros."""
+    ac = nlp.attention_cell
+    rng = np.random.default_rng(4)
+    B, H, Lq, Lm, dv = 2, 3, 5, 7, 6
+    q = torch.zeros(B, H, Lq, 0, dtype=dtype, device='cuda')
+    k = torch.zeros(B, H, Lm, 0, dtype=dtype, device='cuda')
+    vv = rng.standard_normal((B, H, Lm, dv))
+    mask = rng.integers(0, 2, size=(B, Lq, Lm)).astype(np.int32)
+    mask[0, 1, :] = 0
+    mask[:, 0, 0] = 1
+    ctx, (scores, w) = ac.multi_head_dot_attn(q, k, to_dev(vv, dtype), to_dev(mask, torch.int32),
+                                              scaled=False, layout='NKT')
+    from gluonnlp_amd import _lib
+    assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_UNFUSED
+    cnt = mask.sum(-1, keepdims=True)
+    want_w = np.where(mask > 0, 1.0 / np.maximum(cnt, 1), 0.0)[:, None].repeat(H, 1)
+    vq = to_np(to_dev(vv, dtype)).astype(np.float64)
+    want = np.einsum('bhij,bhjd->bihd', want_w, vq).reshape(B, Lq, H * dv)
+    t = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float(np.abs(to_np(scores)).max()) == 0.0
+    assert rel_err(to_np(w), want_w) < t
+    assert rel_err(to_np(ctx), want) < t
+    assert float(np.abs(to_np(ctx)[0, 1]).max()) == 0.0
+

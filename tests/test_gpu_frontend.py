@@ -526,3 +526,32 @@ def test_t5_packed_qkv_follows_parameter_edits(nlp):
     c = mk()
     c.load_state_dict(sd)
     assert torch.equal(c(x, vl), a(x, vl))
+
+
+def test_memory_projections_and_dot_data_edits(nlp):
+    """The documented limit of the kept memory projections (layers.memory_kv): an in-place write
+    through ``.data`` bumps no version counter, so the next step still serves the projections of
+    the OLD weights -- until drop_memory_kv(states); pinned so that the behaviour cannot change
+    silently."""
+    from gluonnlp_amd.layers import drop_memory_kv
+    from gluonnlp_amd.models import TransformerDecoder
+    torch.manual_seed(5)
+    B, LM, U = 2, 6, 64
+    m = TransformerDecoder(num_layers=1, units=U, mem_units=U, hidden_size=128, num_heads=2,
+                           dtype='bfloat16', layout='NT').cuda()
+    for p in m.parameters():
+        p.data.normal_(0, 0.1)
+    mem = torch.randn(B, LM, U, device='cuda').to(torch.bfloat16)
+    mvl = torch.tensor([LM, 3], device='cuda')
+    x = torch.randn(B, U, device='cuda').to(torch.bfloat16)
+    st = m.init_states(B, 'cuda', 'bfloat16')
+    _, st = m.incremental_decode(x, st, mem, mvl)
+    m.layers[0].attn_inter_k.weight.data.mul_(-3.0)          # in place through .data
+    stale, st_stale = m.incremental_decode(x, st, mem, mvl)
+    drop_memory_kv(st)
+    fresh, _ = m.incremental_decode(x, st, mem, mvl)
+    ref_, _ = m.incremental_decode(x, [type(s_)(s_) if isinstance(s_, (list, tuple)) else s_.clone()
+                                       for s_ in st], mem, mvl)   # cloned states carry nothing
+    assert torch.equal(fresh, ref_)
+    assert not torch.equal(stale, fresh)
+

@@ -54,6 +54,33 @@ def _both(lib, layer, x, vl, want_weights, final_seq_mask):
     return outs
 
 
+def test_encoder_layer_noalloc_allocates_nothing():
+    """Free device memory (hipMemGetInfo through torch) is the same before and after a call of the
+    no-alloc entry point, once the device's warm-up call (hipGetSymbolAddress) has been made; a
+    stream of another device than the current one is refused (one-GPU box: not exercised)."""
+    from gluonnlp_amd import _lib, _tensor as T
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    layer, _ = _layer(128, 256, 2, torch.bfloat16, rng)
+    x = to_dev(rng.standard_normal((2, 64, 128)), torch.bfloat16)
+    vl = torch.tensor([64, 9], device='cuda')
+    out = torch.empty_like(x)
+    cfg = layer.cfg_struct(T.code(x))
+    p = layer.params_struct()
+    stream = T.stream(x.device)
+    call = lambda: lib.gnlp_encoder_layer_forward_noalloc(
+        T.ptr(out), T.ptr(x), ctypes.byref(p), ctypes.byref(cfg), 2, 64, None, T.ptr(vl), _lib.I64,
+        None, 1, stream)
+    _lib.check(call())                      # warm-up: the address look-up of this device
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        _lib.check(call())
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_encoder_layer_noalloc_matches_workspace_form(dtype):
     from gluonnlp_amd import _lib
