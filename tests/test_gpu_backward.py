@@ -6,7 +6,11 @@ value / rel_scores after ``out.backward()`` agree across the NKT / NTK / TNK lay
 are additionally compared with known answers: float64 autograd through the reference's PyTorch
 sibling (tests/golden/grad.npz, oracle/gen_golden_grad.py) and the float64 oracle restatement
 (oracle/ref.py: multi_head_dot_attn_backward, layer_norm_backward ...).
-Tolerances: fp32 1e-5, bf16 2e-2 (tests/util.py rel_err: global and element-wise)."""
+Tolerances: fp32 1e-5, bf16 2e-2 (tests/util.py rel_err: global and element-wise).  Where a case
+cannot be held to them by ANY evaluation at the working precision, the bar is MEASURED, not argued:
+tests/util.py attn_backward_floor evaluates the same case plainly at that precision (float32 numpy;
+float64 with the roundings of a bf16-MFMA backward) and the HIP result must stay within
+max(tolerance, 2 x that floor) -- ``bar()`` below.  tests/dev_bwd_floor.py prints both columns."""
 import ctypes
 import os
 
@@ -15,7 +19,7 @@ import pytest
 import torch
 
 from oracle import ref
-from tests.util import prep, rel_err, to_dev, to_np, tol
+from tests.util import attn_backward_floor, prep, rel_err, to_dev, to_np, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +35,12 @@ def nlp():
     _lib.load()
     assert torch.cuda.is_available()
     return gluonnlp_amd
+
+
+def bar(t, floor, exp):
+    """max(t, 2 x the worst error of the plain evaluation ``floor`` against ``exp``)."""
+    worst = max(float(rel_err(f, b)) for f, b in zip(floor, exp) if b is not None)
+    return max(t, 2.0 * worst)
 
 
 def lay(x, perm):
@@ -73,14 +83,19 @@ def test_attention_backward_goldens(nlp, tag, biases, dtype):
         for ename in biases:
             e = None if ename == 'none' else g['{}_e_{}'.format(tag, ename)]
             key = '{}_s{}_{}'.format(tag, scaled, ename)
-            # d = 64 un-scaled: logits ~ N(0, 64) reach |s| ~ 30 where one fp32 ulp is 1.9e-6, so
-            # merely HOLDING a logit in fp32 moves its weight by ~1e-6 relative and D = sum(P dP)
-            # (|dP| ~ 8) by ~1e-5: the element-wise floor of any fp32 evaluation of this case
-            te = 1e-4 if (tag == 'd64' and not scaled and dtype == torch.float32) else t
             if dtype == torch.float32:
                 exp = [g[key + '_' + n] for n in ('ctx', 'dq', 'dk', 'dv')]
                 exp.append(g[key + '_de'] if e is not None else None)
+                # d = 64 un-scaled: logits ~ N(0, 64) reach |s| ~ 30 where one fp32 ulp is 1.9e-6:
+                # merely HOLDING a logit in fp32 moves its weight by ~1e-6 relative.  The float32
+                # numpy evaluation of the case measures 0.5-1.0e-5 there (HIP: 0.5-1.7e-5), so
+                # the bar is max(1e-5, 2 x floor) ~ 2e-5 (it was an argued 1e-4)
+                te = t
+                if tag == 'd64' and not scaled:
+                    te = bar(t, attn_backward_floor(gc, q, k, v, mask, e, False, 'f32'), exp)
+                    assert te < 3e-5
             else:   # what the device holds is the bf16 rounding of the inputs
+                te = t
                 pq, pk, pv, pg = [prep(x, dtype) for x in (q, k, v, gc)]
                 pe = None if e is None else prep(e, dtype)
                 ectx, _ = ref.multi_head_dot_attn(pq, pk, pv, mask, pe, scaled=bool(scaled),
@@ -120,16 +135,23 @@ def test_attention_backward_valid_length_predicate(nlp, dtype):
         for name, x in zip(('ctx', 'dq', 'dk', 'dv', 'de'), a):
             assert rel_err(x, g['d64_s1_head_' + name]) < 1e-5, name
     # the fused bf16 forward (nothing but ctx wanted) hands its row statistics to the backward,
-    # which then takes D = <dO, O> instead of recomputing it: same gradients up to bf16 rounding
-    # (3e-2: the bound of the bf16-MFMA backward, see its own test below)
+    # which then takes D = <dO, O> instead of recomputing it: both against the oracle on the
+    # bf16-rounded inputs, bar = max(2e-2, 2 x measured floor) (measured 0.7-1.1e-2 = the floor of
+    # rounding the outputs to bf16 alone; it was an argued 3e-2 against the UNROUNDED inputs' golden)
     if dtype == torch.bfloat16:
         c = run_attn(ac, 'NTK', (0, 2, 1, 3), q, k, v, mask, e, gc, True, dtype, d,
                      _need_scores=False, _need_weights=False)
         from gluonnlp_amd import _lib
         assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_FUSED_BF16
-        for name, x, y in zip(('dq', 'dk', 'dv', 'de'), a[1:], c[1:]):
-            assert rel_err(y, g['d64_s1_head_' + name]) < 3e-2, name
-            assert rel_err(y, x) < 3e-2, name
+        pq, pk, pv, pg, pe = [prep(x, dtype) for x in (q, k, v, gc, e)]   # what the device holds
+        mk = mask.cpu().numpy()
+        exp = ref.multi_head_dot_attn_backward(pg, pq, pk, pv, mk, pe, scaled=True,
+                                               query_head_units=d)
+        tb = bar(tol(dtype), attn_backward_floor(pg, pq, pk, pv, mk, pe, True, 'bf16')[1:], exp)
+        assert tb < 2.5e-2
+        for name, x, y, w in zip(('dq', 'dk', 'dv', 'de'), a[1:], c[1:], exp):
+            assert rel_err(y, w) < tb, name
+            assert rel_err(x, w) < tb, name
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -159,7 +181,9 @@ def test_attention_backward_memory_mask_predicate(nlp, dtype, Lq, Lm, d, fused):
     want = [ref.multi_head_dot_attn(pq, pk, pv, mask_np, pe, scaled=True, query_head_units=d)[0]] + \
         list(ref.multi_head_dot_attn_backward(pg, pq, pk, pv, mask_np, pe, scaled=True,
                                               query_head_units=d))
-    t = 1e-5 if dtype == torch.float32 else 3e-2
+    t = tol(dtype)
+    if dtype == torch.bfloat16:   # the bf16-MFMA pair: held to max(2e-2, 2 x the measured floor)
+        t = min(bar(t, attn_backward_floor(pg, pq, pk, pv, mask_np, pe, True, 'bf16'), want), 3e-2)
     for name, x, y, w in zip(('ctx', 'dq', 'dk', 'dv', 'de'), a, b, want):
         assert np.isfinite(x).all(), name
         assert rel_err(x, y) < t, name
@@ -442,8 +466,9 @@ def test_attention_backward_bf16_kernels_without_bias(nlp, attn_type, B, H, L, v
     rms(ref) against 0.0017 from rounding the exact gradient to bf16 alone (what the fp32-MFMA
     path shows), but heavy-tailed: early keys under the causal mask carry a few large dS terms
     that cancel in the sum, and one element of dk reaches 2.02e-2 on the element-wise metric.
-    Hence 3e-2 for the bf16-MFMA path here; the fp32-MFMA path is held to the 2e-2 of every other
-    bf16 test."""
+    The bar of the bf16-MFMA path is therefore max(2e-2, 2 x the floor MEASURED on the case by
+    tests/util.py attn_backward_floor with the same roundings -- 2.02e-2 on the causal case: the
+    plain evaluation shows the same heavy tail), and never more than 3e-2; the fp32-MFMA path is held to the 2e-2 of every other bf16 test."""
     from gluonnlp_amd import _lib
     ac = nlp.attention_cell
     d = 64
@@ -470,18 +495,23 @@ def test_attention_backward_bf16_kernels_without_bias(nlp, attn_type, B, H, L, v
     pq, pk, pv, pg = [prep(x, dtype) for x in (q, k, v, gc)]
     exp = ref.multi_head_dot_attn_backward(pg, pq, pk, pv, dense.cpu().numpy(), None, scaled=True,
                                            query_head_units=d)
+    live = float(max(np.abs(y).max() for y in exp[:3])) > 0.0
+    tb = tol(dtype)
+    if live:
+        fl = attn_backward_floor(pg, pq, pk, pv, dense.cpu().numpy(), None, True, 'bf16')
+        tb = min(bar(tb, fl[1:4], exp[:3]), 3e-2)   # the causal case's floor itself is 2.02e-2
     for name, x, y, z in zip(('dq', 'dk', 'dv'), a[1:4], exp[:3], c[1:4]):
         if float(np.abs(y).max()) == 0.0:
             assert float(np.abs(x).max()) == 0.0 and float(np.abs(z).max()) == 0.0, name
             continue
-        assert rel_err(x, y) < 3e-2, name
+        assert rel_err(x, y) < tb, name
         assert rel_err(z, y) < tol(dtype), name
-        assert rel_err(x, z) < 3e-2, name
+        assert rel_err(x, z) < tb, name
     for name, x, y in zip(('dq', 'dk', 'dv'), f[1:4], exp[:3]):
         if float(np.abs(y).max()) == 0.0:
             assert float(np.abs(x).max()) == 0.0, name
         else:
-            assert rel_err(x, y) < 3e-2, name
+            assert rel_err(x, y) < tb, name
 
 
 @pytest.mark.parametrize('layout,perm', LAYOUTS)
@@ -507,9 +537,11 @@ def test_attention_backward_with_forward_statistics(nlp, layout, perm):
     got = run_attn(ac, layout, perm, q, k, v, torch.tensor(mask, device='cuda'), e, gc, True,
                    dtype, d, _need_scores=False, _need_weights=False)
     assert _lib.load().gnlp_attn_last_kernel() == _lib.ATTN_KERNEL_FUSED_BF16
+    tb = min(bar(tol(dtype), attn_backward_floor(pg, pq, pk, pv, mask, pe, True, 'bf16')[1:], exp),
+             3e-2)
     for name, x, y in zip(('dq', 'dk', 'dv', 'de'), got[1:], exp):
         assert x.shape == y.shape
-        assert rel_err(x, y) < 3e-2, (layout, name)
+        assert rel_err(x, y) < tb, (layout, name)
     # the saved tensors come together
     lib = _lib.load()
     dd = _lib.AttnDesc()

@@ -133,7 +133,8 @@ def test_cfg5_large_fp32_and_bf16_full_size(nlp, kind, eps):
 
 def test_cfg4_t5_base_full_size(nlp):
     """T5-base encoder, 12 blocks, B=16, L=1024, bf16, relative-position bias: buckets bit-exact,
-    whole sequences against the oracle, batch permutation bit for bit."""
+    every block against the oracle block at 2e-2, whole sequences against the oracle at full depth,
+    batch permutation bit for bit."""
     from gluonnlp_amd.models import T5Encoder
     ac = nlp.attention_cell
     rng = np.random.default_rng(305)
@@ -162,6 +163,36 @@ def test_cfg4_t5_base_full_size(nlp):
                           ref.relative_position_bucket(ref.gen_rel_position((B, L)), True, 32, 128))
     pick = [0, B - 1]
     o = lambda a: prep(a, dtype)
+    # (1a) every block at full size, as _stack_case does for the BERT-shaped stacks: block i alone
+    # through the same C entry (one block, no final norm) on the device's output of block i - 1,
+    # the oracle block on that same input -- rounding does not accumulate in the comparison, so
+    # each block is held to the plain 2e-2 (the end-to-end check below carries sqrt(layers))
+    from gluonnlp_amd.models.t5 import run_t5_blocks
+    table = enc.relative_position_encoder.self_attn_bias_table(L)
+    pos = ref.rel_attention_score_t5(o(relw), ref.gen_rel_position((len(pick), L)),
+                                     bidirectional=True, num_buckets=32, max_distance=128)
+    mask = ref.gen_self_attn_mask((len(pick), L), vl[pick])
+    prev_d, prev = xd, o(x[pick])
+    worst_block, worst_at = 0.0, -1
+    idx = torch.tensor(pick, device='cuda')
+    for i in range(NL):
+        prev_d = run_t5_blocks([enc.layers[i]], prev_d, vld, table, None, 'NT', toeplitz=True)
+        want_i = ref.t5_block(prev, mask, pos, {k: o(v) for k, v in lps[i].items()}, H,
+                              activation_name='relu')
+        got_i = to_np(prev_d[idx])
+        for j, b in enumerate(pick):
+            n = vl[b]
+            e = float(rel_err(got_i[j, :n], want_i[j, :n]))
+            if e > worst_block:
+                worst_block, worst_at = e, i
+            assert e < tol(dtype), ('t5 block', i, 'seq', b)
+        prev = got_i
+    print('[fullsize] t5_base bf16 L=1024 B=16: worst per-block err {:.3e} at block {} (tol {:.0e})'
+          .format(worst_block, worst_at, tol(dtype)))
+    # the chain of single-block calls is the stack without its final norm: same kernels, same bits
+    fin_d = enc.final_layer_norm(prev_d)
+    keep_all = torch.arange(L, device='cuda')[None, :] < vld[:, None]
+    assert torch.equal(fin_d[keep_all], out[keep_all])
     want = ref.t5_encoder(o(x[pick]), vl[pick], o(relw),
                           [{k: o(v) for k, v in p.items()} for p in lps],
                           {k: o(v) for k, v in fin.items()}, H, activation_name='relu')

@@ -91,3 +91,47 @@ def load_params(module, params, dtype, dev='cuda'):
 
 def oracle_params(params, dtype):
     return {k: prep(v, dtype) for k, v in params.items()}
+
+
+def attn_backward_floor(g_ctx, q, k, v, mask, e, scaled, mode):
+    """A plain evaluation of multi_head_dot_attn and its gradients (NKT layout, oracle/ref.py's
+    formulas) at a stated working precision -- NOT the oracle, but the measured FLOOR a widened
+    tolerance is held against (the error any evaluation at that precision shows on the case):
+      mode 'f32'  : every array and every product in float32 (numpy float32 matmul);
+      mode 'bf16' : float64 arithmetic on bf16 inputs with the roundings of a bf16-MFMA backward:
+                    P and dS rounded to bf16 before the second matrix products, outputs to bf16.
+    -> ctx (B, Lq, H*dv), dq, dk, dv, de (shape of e, or None)."""
+    ft = np.float32 if mode == 'f32' else np.float64
+    rnd = (lambda a: a) if mode == 'f32' else bf16_round
+    q, k, v = [np.asarray(a).astype(ft) for a in (q, k, v)]
+    B, H, Lq, d = q.shape
+    dvu = v.shape[-1]
+    g = np.asarray(g_ctx).astype(ft).reshape(B, Lq, H, dvu).transpose(0, 2, 1, 3)
+    scale = ft(np.sqrt(ft(d))) if scaled else ft(1)
+    s = np.matmul(q, np.swapaxes(k, -1, -2))
+    if e is not None:
+        s = s + np.asarray(e).astype(ft)
+    m = np.broadcast_to(np.asarray(mask).astype(bool)[:, None], s.shape)
+    s = np.where(m, s / scale, ft(-np.inf))
+    mx = s.max(-1, keepdims=True)
+    mx = np.where(np.isfinite(mx), mx, ft(0))
+    p = np.where(m, np.exp(s - mx), ft(0))
+    den = p.sum(-1, keepdims=True)
+    p = (p / np.where(den > 0, den, ft(1))).astype(ft)
+    ctx = np.matmul(rnd(p), v).transpose(0, 2, 1, 3).reshape(B, Lq, H * dvu)
+    d_v = np.matmul(np.swapaxes(rnd(p), -1, -2), g)
+    d_p = np.matmul(g, np.swapaxes(v, -1, -2))
+    d_s = (p * (d_p - (d_p * p).sum(-1, keepdims=True)) / scale).astype(ft)
+    d_q = np.matmul(rnd(d_s), k)
+    d_k = np.matmul(np.swapaxes(rnd(d_s), -1, -2), q)
+    d_e = None
+    if e is not None:
+        es = np.asarray(e).shape
+        full = (1,) * (4 - len(es)) + tuple(es)
+        d_e = d_s
+        for ax, n in enumerate(full):
+            if n == 1 and d_e.shape[ax] != 1:
+                d_e = d_e.sum(axis=ax, keepdims=True)
+        d_e = d_e.reshape(es)
+    return [rnd(np.asarray(a, dtype=np.float64)) if a is not None else None
+            for a in (ctx, d_q, d_k, d_v, d_e)]
