@@ -168,6 +168,54 @@ def count_ranks(dist, device):
     return int(round(float(t.item())))
 
 
+def run_protocol(step, wait_gather, sync, dist, dev, steps, warmup, rank, rank0_block):
+    """Everything between "model built" and "process group torn down", with the device work
+    injected (tests/test_dist_gloo.py runs it on two gloo ranks with a stub step):
+      W untimed steps; barrier; K timed steps + wait_gather(); barrier; MAX of the elapsed time over
+      the ranks; then the reference harness's own protocol (benchmark_utils.py:843-844: min over 3
+      repeats of 3 forwards / 3) and the median of 20 single forwards ON EVERY RANK -- step()
+      issues a collective when the job has more than one rank, so every rank makes the same calls;
+      then rank 0 ALONE in rank0_block (nothing in it may issue a collective); a final barrier holds
+      the other ranks until rank 0 has printed.
+    ``dist`` is torch.distributed or None (single process); ``sync`` waits for the device."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    wait_gather()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    def timed(n):
+        sync()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        sync()
+        return (time.perf_counter() - t) / n * 1e3
+    harness_ms = min(timed(3) for _ in range(3))
+    median_ms = float(np.median([timed(1) for _ in range(20)]))
+    wait_gather()
+    if rank == 0:
+        rank0_block(elapsed, harness_ms, median_ms, out)
+    if dist is not None:
+        dist.barrier()
+    return elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -248,41 +296,7 @@ def main():
             return ctx, pooled
         step_no_collective = step   # noqa: F811
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    runner.wait_gather()
-    torch.cuda.synchronize(dev)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out[0].float()).all()
-
-    # The reference harness's own protocol (benchmark_utils.py:843-844: min over 3 repeats of 3
-    # forwards / 3, after the warm-up) and the median of 20 single forwards, device-synchronised;
-    # reported beside the contract's K-step figure, never instead of it.
-    def timed(n):
-        torch.cuda.synchronize(dev)
-        t = time.perf_counter()
-        for _ in range(n):
-            step()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t) / n * 1e3
-    harness_ms = min(timed(3) for _ in range(3))
-    median_ms = float(np.median([timed(1) for _ in range(20)]))
-
-    if rank == 0:
+    def rank0_report(elapsed, harness_ms, median_ms):
         seqs = world * B * args.steps / elapsed
         fps = flops_per_seq(U, F, layers, L)
         vls = vl.to(torch.float64)
@@ -348,8 +362,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline and kind != 't5':
             line['cpu_baseline'] = cpu_baseline(kind, U, H, F, layers, L, eps, args.cpu_sample)
         print(json.dumps(line), flush=True)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    def report(elapsed, harness_ms, median_ms, out):
+        assert torch.isfinite(out[0].float()).all()
+        rank0_report(elapsed, harness_ms, median_ms)
+
+    run_protocol(step, runner.wait_gather, sync, dist if dist_on else None, dev, args.steps,
+                 args.warmup, rank, report)
     if dist_on:
-        dist.barrier()
         dist.destroy_process_group()
 
 

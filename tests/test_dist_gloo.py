@@ -110,3 +110,72 @@ def test_bench_count_ranks_world2():
     ret = mgr.dict()
     mp.spawn(_count_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: 2, 1: 2}
+
+
+# ---- bench.py's control flow after the build, on two gloo ranks with a stub step -------------------
+def _protocol_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    b = _bench()
+    calls = {'step': 0, 'alone': 0, 'gather_waits': 0, 'report': 0}
+    dev = torch.device('cpu')
+
+    def step():                      # like the real step: one collective per call
+        calls['step'] += 1
+        t = torch.full((1,), float(rank))
+        got = [torch.empty(1) for _ in range(world)]
+        dist.all_gather(got, t)
+        return (torch.cat(got),)
+
+    def step_alone():                # like encode_local: no collective
+        calls['alone'] += 1
+
+    def wait_gather():
+        calls['gather_waits'] += 1
+
+    def rank0_block(elapsed, harness_ms, median_ms, out):
+        # what rank 0 does alone in bench.py: repeat the forward WITHOUT its collective, a
+        # different number of times than anything the other rank does, and take its time over it
+        calls['report'] += 1
+        import time
+        for _ in range(7):
+            step_alone()
+        time.sleep(0.5)
+        assert elapsed > 0 and harness_ms > 0 and median_ms > 0
+        assert out[0].tolist() == [0.0, 1.0]
+
+    elapsed = b.run_protocol(step, wait_gather, lambda: None, dist, dev, 4, 2, rank, rank0_block)
+    # the MAX over the ranks: both ranks hold the same figure
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    lo = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    ret[rank] = dict(calls, same_elapsed=bool(t.item() == lo.item()))
+    dist.destroy_process_group()
+
+
+def test_bench_protocol_world2_every_rank_makes_the_same_collective_calls():
+    """the post-timing part of bench.py (every rank in the harness-protocol
+    repeats, rank 0 alone in the roofline block, final barrier) on two gloo ranks.  A rank that
+    skipped the repeats, or a collective inside rank 0's block, would leave the other rank in a
+    collective nobody answers: the workers are joined under a time limit."""
+    world = 2
+    port = 29950 + (os.getpid() % 40)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.spawn(_protocol_worker, args=(world, port, ret), nprocs=world, join=False)
+    import time
+    deadline = time.time() + 120
+    while not ctx.join(timeout=1.0):
+        if time.time() > deadline:
+            for p in ctx.processes:          # the exact processes this test started
+                p.kill()
+            pytest.fail('bench.run_protocol hung on two ranks')
+    r = dict(ret)
+    n_steps = 2 + 4 + 3 * 3 + 20                 # warm-up, timed, harness protocol, median of 20
+    assert r[0]['step'] == r[1]['step'] == n_steps
+    assert r[0]['report'] == 1 and r[1]['report'] == 0
+    assert r[0]['alone'] == 7 and r[1]['alone'] == 0
+    assert r[0]['gather_waits'] == r[1]['gather_waits'] == 2
+    assert r[0]['same_elapsed'] and r[1]['same_elapsed']
