@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on one box: tools/ab.sh libA.so libB.so ...  (interleaved, 2 rounds)
+# A/B of library builds on one box: tools/archive/ab.sh libA.so libB.so ...  (interleaved, 2 rounds)
 for r in 1 2; do
   for lib in "$@"; do
     echo "== $lib"

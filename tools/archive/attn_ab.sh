@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool: the fused attention kernel's time at the BERT-large shape under variant builds
-# of the library (tools/mkvar.sh), alternating, two rounds.   bash tools/attn_ab.sh name1 name2 ...
+# of the library (tools/mkvar.sh), alternating, two rounds.   bash tools/archive/attn_ab.sh name1 name2 ...
 for rnd in 1 2; do
   for l in "$@"; do
     if [ "$l" == default ]; then unset GNLP_LIB_PATH; else export GNLP_LIB_PATH=$PWD/tools/build/var/lib_$l.so; fi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool: kernel times of tools/bwd_one.py under variant builds of the library
-#   gpurun -- bash tools/bwd_exp.sh tools/build/a/libgluonnlp_amd.so tools/build/b/libgluonnlp_amd.so
+#   gpurun -- bash tools/archive/bwd_exp.sh tools/build/a/libgluonnlp_amd.so tools/build/b/libgluonnlp_amd.so
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/bwd_exp
 mkdir -p $OUT

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/clock
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $OUT/p -o p --output-format csv -- python $R/tools/gemm_power.py > $OUT/log.txt 2>&1 || tail -5 $OUT/log.txt
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $OUT/p -o p --output-format csv -- python $R/tools/archive/gemm_power.py > $OUT/log.txt 2>&1 || tail -5 $OUT/log.txt
 python - <<PY
 import csv, glob, collections
 cc = glob.glob('$OUT/p/**/*counter_collection.csv', recursive=True)[0]

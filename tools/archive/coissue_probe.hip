@@ -2,7 +2,7 @@
 // 512-thread workgroup: waves 0-3 (one per SIMD) run an MFMA loop, waves 4-7 (their SIMD partners)
 // a softmax-like VALU loop (v_pk_fma_f32 + v_exp_f32 + v_cvt_pk_bf16_f32).  Each mode is timed with
 // the shader clock per wave: MFMA alone, VALU alone, both together.
-//   hipcc --offload-arch=gfx950 -O3 -o tools/build/coissue_probe tools/coissue_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -o tools/build/coissue_probe tools/archive/coissue_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

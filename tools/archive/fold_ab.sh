@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool: bench.py with the LayerNorm fold off / on, alternating, under the default library
-# or variant builds (tools/mkvar.sh).   bash tools/fold_ab.sh [name ...]
+# or variant builds (tools/mkvar.sh).   bash tools/archive/fold_ab.sh [name ...]
 LIBS=("$@"); [ ${#LIBS[@]} -eq 0 ] && LIBS=(default)
 for rnd in 1 2; do
   for l in "${LIBS[@]}"; do

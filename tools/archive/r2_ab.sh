@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (round 2): correctness of the dense tests on the default build, then the isolated
 # GEMM shapes and the forward for the default build against variant libraries, alternating.
-#   gpurun -- bash tools/r2_ab.sh tools/build/base/libgluonnlp_amd.so
+#   gpurun -- bash tools/archive/r2_ab.sh tools/build/base/libgluonnlp_amd.so
 set -e
 mkdir -p gpurun_out
 timeout -k 10 400 python -u -m pytest tests/test_gpu_ops.py -q -x -k "dense" --timeout 200 --timeout-method thread > gpurun_out/ab_tests.log 2>&1 || { tail -30 gpurun_out/ab_tests.log; exit 1; }
