@@ -141,6 +141,13 @@ __device__ __forceinline__ float w4_oct_sum(float x) {
   return x;
 }
 
+// weight row (inside a block of 32) that lands in LDS row x of the block in the DIRECT drain's
+// instantiations: bits (b4 b3 b2 b1 b0) -> (b3 b2 b4 b1 b0), so that MFMA output row
+// 16 (j & 1) + 4 g + e of weight fragment j is column 8 g + 4 (j & 1) + e of the block
+__device__ __forceinline__ int w4_perm5(int x) {
+  return (x & 3) | ((x & 16) >> 2) | ((x & 12) << 1);
+}
+
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 #define W4_BAR()                       \
   do {                                 \
@@ -165,6 +172,12 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 #if __HIP_DEVICE_COMPILE__   // (the buffer-resource builtins exist in the device pass only)
   static_assert(NJ == 8 || NJ == 6, "256- or 192-wide tiles");
   static_assert(FOLD == 0 || (FOLD == 1 && !HAS_OTHER) || (FOLD == 2 && HAS_OTHER), "fold modes");
+  // DIRECT: the drain stores straight from the accumulator layout (no LDS transpose): the
+  // instantiations with an activation, whose drains are bound by their vector-ALU work.  The
+  // identity drains are bound by the memory system (every CU stores at once) and keep the
+  // transpose with its whole-line stores: measured, DESIGN.md section 6c.
+  constexpr bool DIRECT = ACT != GNLP_ACT_IDENTITY;
+  static_assert(!(DIRECT && FOLD == 2), "FOLD 2 is an identity drain");
   constexpr int NT = 32 * NJ;            // tile width
   constexpr int NQ = NJ / 2;             // 32-row pieces of a B half-panel per wave
   constexpr int HALF = 128 * 128;        // bytes of one half-panel slot (128 rows x 64 bf16)
@@ -205,7 +218,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
     const int row = wave * 8 + srow;
     const int c = cpos ^ ((row >> 1) & 7);
     offA = (unsigned)(row * (int)a.ldx + c * 8) * 2u;
-    offB = (unsigned)(row * a.K + c * 8) * 2u;
+    // (DIRECT: permuted weight rows, see the drain; the swizzle stays keyed by the LDS row)
+    offB = (unsigned)((DIRECT ? w4_perm5(row) : row) * a.K + c * 8) * 2u;
   }
   int soffA[8], soffB[NJ];   // byte offsets of the pieces inside a K-tile panel (uniform)
 #pragma unroll
@@ -322,7 +336,7 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   };
   constexpr bool RING = HAS_OTHER;
   constexpr int NL = 4;   // operations of one L group
-  constexpr int RD = FOLD == 2 ? 2 : 3;   // ring depth (FOLD 2 holds both rings: registers)
+  constexpr int RD = (FOLD == 2 || ACT == GNLP_ACT_GELU_TANH) ? 2 : 3;   // ring depth (registers)
   constexpr int NST = FOLD == 2 ? 8 : 4;  // stores of one S group (FOLD 2: + the rows' statistics)
   constexpr int WCOLS = NT / 2;
   bf16x8 ring[RD][2][2];     // residual / gate rows of RD slabs (HAS_OTHER)
@@ -352,6 +366,18 @@ dense_bf16_w4_kernel(DenseW4Args a) {
   auto fold_head = [&](int m0, int n0) __attribute__((always_inline)) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    if constexpr (DIRECT) {   // 8 rows per lane, m0 + 128 wm + (lane & 15) + 16 s; c, b' sit in LDS
+      const float *rp = a.rstats + ((int64_t)m0 + wm * 128 + (ln & 15)) * 2;
+#define W4_RST_LD(j)                                            \
+  asm volatile("global_load_dwordx2 %0, %1, off offset:%2"      \
+               : "=&v"(rst[j])                                  \
+               : "v"(rp), "n"((j) * 128)                        \
+               : "memory")
+      W4_RST_LD(0); W4_RST_LD(1); W4_RST_LD(2); W4_RST_LD(3);
+      W4_RST_LD(4); W4_RST_LD(5); W4_RST_LD(6); W4_RST_LD(7);
+#undef W4_RST_LD
+      return;
+    }
     if constexpr (FOLD == 1) {
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn)
@@ -538,6 +564,139 @@ dense_bf16_w4_kernel(DenseW4Args a) {
       });
     });
   };
+  // ---- DIRECT drain (activations): no transpose ----
+  // The MFMA's A operand is the WEIGHT fragment, so lane (g = lane >> 4, r = lane & 15) holds, in
+  // acc[j][s], row 16 s + r of the wave's block and the 4 columns 4 g .. 4 g + 3 of weight fragment
+  // j; the staging permutes the weight rows inside every block of 32 (w4_perm5) so that fragments
+  // 2 p and 2 p + 1 together give the lane the 8 CONSECUTIVE columns 32 p + 8 g .. + 7: one
+  // 16-byte store per (s, p), 16 rows x 64 contiguous bytes per instruction.  The fp32 round trip
+  // of the accumulators through LDS (512 KiB per tile and CU) is gone; the per-column vectors
+  // (bias; FOLD 1: b' and c as fp32) come from LDS images written in the prologue.
+  // Slab k = 4 hn + sp: rows 32 sp .. + 31 of the wave's block (row fragments s = 2 sp, 2 sp + 1) x
+  // the 64-column group hn (pairs p = 2 hn, 2 hn + 1; NJ = 6: group 1 is pair 2 alone).
+  constexpr int NP = NJ / 2;
+  auto d_pairs = [](int k) constexpr { return NP - (k >> 2) * 2 < 2 ? NP - (k >> 2) * 2 : 2; };
+  auto slab_loads_direct = [&](int m0, int n0, int ln, int k) __attribute__((always_inline)) {
+    const int hn = k >> 2, sp = k & 3;
+    const bf16 *op = a.other + ((int64_t)m0 + wm * 128 + sp * 32 + (ln & 15)) * a.ldother + n0 +
+                     wn * WCOLS + hn * 64 + (ln >> 4) * 8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+        if (pp < d_pairs(k)) gload(ring[k % RD][q][pp], op + q * 16 * a.ldother + pp * 32);
+  };
+  auto drain_direct = [&](int m0, int n0) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    // wait for the loads of slab k: L(k + 1) .. L(k + RD - 1) and S(k - RD + 1) .. S(k - 1) may
+    // stay in flight (2 d_pairs operations per L and per S)
+    auto slab_wait = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int FLY = [=]() constexpr {
+        int n = 0;
+        for (int j = k + 1; j <= k + RD - 1 && j < 8; ++j) n += 2 * d_pairs(j);
+        for (int j = k - RD + 1 > 0 ? k - RD + 1 : 0; j < k; ++j) n += 2 * d_pairs(j);
+        return n;
+      }();
+      bf16x8(&r)[2][2] = ring[k % RD];
+      asm volatile("s_waitcnt vmcnt(%4)"
+                   : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])
+                   : "n"(FLY)
+                   : "memory");
+    };
+    if (RING) {
+      slab_loads_direct(m0, n0, ln, 0);
+      if (RD == 3) slab_loads_direct(m0, n0, ln, 1);
+    }
+    w4_static_for<2>([&](auto hnc) __attribute__((always_inline)) {   // 64-column groups
+      constexpr int hn = decltype(hnc)::value;
+      constexpr int PPN = NP - hn * 2 < 2 ? NP - hn * 2 : 2;          // pairs of this group: 2 or 1
+      asm volatile("" : "+v"(ln));   // (lane-derived addresses are recomputed per group: registers)
+      const int g = ln >> 4, r16 = ln & 15;
+      const int nloc = wn * WCOLS + hn * 64 + g * 8;   // the lane's 8 columns of pair pp: + 32 pp
+      f32x2 bv[2][4], cv[2][4];   // FOLD 0: bv = bias;  FOLD 1: bv = b', cv = c
+#pragma unroll
+      for (int pp = 0; pp < PPN; ++pp) {
+        const int n = n0 + nloc + pp * 32;
+        if constexpr (FOLD == 0) {
+          const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(smem + BIAS + n * 2);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bv[pp][c] = (f32x2){(float)b8[2 * c], (float)b8[2 * c + 1]};
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(smem + BIAS + (n + h * 4) * 4);
+            const f32x4 c4 = *reinterpret_cast<const f32x4 *>(smem + SCRATCH + (n + h * 4) * 4);
+            bv[pp][2 * h] = (f32x2){b4[0], b4[1]}; bv[pp][2 * h + 1] = (f32x2){b4[2], b4[3]};
+            cv[pp][2 * h] = (f32x2){c4[0], c4[1]}; cv[pp][2 * h + 1] = (f32x2){c4[2], c4[3]};
+          }
+        }
+      }
+      w4_static_for<4>([&](auto spc) __attribute__((always_inline)) {   // 32-row slabs
+        constexpr int sp = decltype(spc)::value;
+        constexpr int k = hn * 4 + sp;
+        if constexpr (RING) {
+          if constexpr (k + RD - 1 < 8) slab_loads_direct(m0, n0, ln, k + RD - 1);
+          slab_wait(std::integral_constant<int, k>{});
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int s = 2 * sp + q;
+          const int64_t mrow = (int64_t)m0 + wm * 128 + s * 16 + r16;
+          [[maybe_unused]] f32x2 r2, nm2;
+          if constexpr (FOLD == 1) {
+            r2 = (f32x2){rst[s][0], rst[s][0]};
+            nm2 = (f32x2){-rst[s][1], -rst[s][1]};
+          }
+          bf16 *orow = a.out + mrow * a.ldo + n0 + nloc;
+#pragma unroll
+          for (int pp = 0; pp < PPN; ++pp) {
+            const int p = hn * 2 + pp;
+            const f32x4 a0 = acc[2 * p][s], a1 = acc[2 * p + 1][s];
+            // pairs throughout (v_pk_fma_f32 / v_cvt_pk_bf16_f32)
+            f32x2 gg[4] = {(f32x2){a0[0], a0[1]}, (f32x2){a0[2], a0[3]}, (f32x2){a1[0], a1[1]},
+                           (f32x2){a1[2], a1[3]}};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if constexpr (FOLD == 1)   // r acc + (b' - (r mu) c)
+                gg[c] = gg[c] * r2 + (cv[pp][c] * nm2 + bv[pp][c]);
+              else
+                gg[c] = gg[c] + bv[pp][c];
+            }
+            if (ACT == GNLP_ACT_GELU_ERF) {
+              gelu_erf_fast2_n<4>(gg);
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                gg[c] = (f32x2){apply_act<false>(gg[c][0], ACT), apply_act<false>(gg[c][1], ACT)};
+                if constexpr (ACT == GNLP_ACT_GELU_TANH) W4_SB();   // (registers)
+              }
+            }
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[2 * c] = gg[c][0]; v[2 * c + 1] = gg[c][1]; }
+            if constexpr (HAS_OTHER) {
+              const bf16x8 o8 = ring[k % RD][q][pp];
+              if (a.combine == GNLP_COMBINE_MUL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= (float)o8[e];
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)o8[e];
+              }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x8 *>(orow + pp * 32) = o;
+            W4_SB();   // 8 columns of a row at a time: registers (no spills)
+          }
+        }
+        W4_SB();   // a slab at a time; its stores are issued before the next slab's loads
+      });
+    });
+  };
   // ---- producer cursor: the next K-tile to request, running ahead of the MFMAs by two ----
   const int nk = a.nk;
   int p_tile = 0, p_kt = 0;
@@ -564,7 +723,12 @@ dense_bf16_w4_kernel(DenseW4Args a) {
 
   // ---- the bias vector goes to LDS once (zeros without a bias) ----
   const bool has_bias = a.bias != nullptr;
-  if constexpr (FOLD == 2) {   // fp32 image (N <= 2048): bias + beta at BIAS, gamma at BIAS + 8 KiB
+  if constexpr (DIRECT && FOLD == 1) {   // b' (fp32) at BIAS, c (fp32) at SCRATCH: N <= 4096
+    for (int i = threadIdx.x * 4; i < a.tiles_n * NT; i += 256 * 4) {
+      *reinterpret_cast<f32x4 *>(smem + BIAS + i * 4) = *reinterpret_cast<const f32x4 *>(a.fold_b + i);
+      *reinterpret_cast<f32x4 *>(smem + SCRATCH + i * 4) = *reinterpret_cast<const f32x4 *>(a.fold_c + i);
+    }
+  } else if constexpr (FOLD == 2) {   // fp32 image (N <= 2048): bias + beta at BIAS, gamma at BIAS + 8 KiB
     for (int i = threadIdx.x * 8; i < a.tiles_n * NT; i += 256 * 8) {
       const bf16x8 g8 = *reinterpret_cast<const bf16x8 *>(a.ln_g + i);
       const bf16x8 t8 = *reinterpret_cast<const bf16x8 *>(a.ln_b + i);
@@ -634,7 +798,8 @@ dense_bf16_w4_kernel(DenseW4Args a) {
       advance();
       par ^= 1;
     }
-    drain(m0, n0);
+    if constexpr (DIRECT) drain_direct(m0, n0);
+    else drain(m0, n0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two requests past the end
 #ifdef W4_STAMP
@@ -719,10 +884,14 @@ static void launch_w4_act(const DenseW4Args &a, hipStream_t s) {
 
 template <int ACT>
 static void launch_w4_other(const DenseW4Args &a, int nt_width, int fold, hipStream_t s) {
-  if (fold == 1) {   // (mfma_bf16_dense_w4_fold_supported: no `other`)
-    if (nt_width == 192) launch_w4_act<ACT, false, 6, 1>(a, s);
-    else launch_w4_act<ACT, false, 8, 1>(a, s);
-  } else if (nt_width == 192) {
+  if constexpr (ACT != GNLP_ACT_GELU_TANH) {
+    if (fold == 1) {   // (mfma_bf16_dense_w4_fold_supported: no `other`, not the tanh GELU)
+      if (nt_width == 192) launch_w4_act<ACT, false, 6, 1>(a, s);
+      else launch_w4_act<ACT, false, 8, 1>(a, s);
+      return;
+    }
+  }
+  if (nt_width == 192) {
     if (a.other) launch_w4_act<ACT, true, 6, 0>(a, s);
     else launch_w4_act<ACT, false, 6, 0>(a, s);
   } else {
@@ -738,6 +907,9 @@ int64_t fold_stat_slots(int64_t M, int64_t N) {
 
 bool mfma_bf16_dense_w4_fold_supported(const DenseFold &f, int act, int combine,
                                        const void *other, int64_t N) {
+  // (mode 1 with an activation: b' and c as fp32 LDS images of 16 KiB each, N <= 4096; not
+  // instantiated for the tanh GELU, which no post-norm stack uses)
+  if (f.mode == 1 && (act == GNLP_ACT_GELU_TANH || (act != GNLP_ACT_IDENTITY && N > 4096))) return false;
   if (f.mode == 1)
     return !other && f.rstats && f.c && f.b && ((uintptr_t)f.c | (uintptr_t)f.b) % 16 == 0 &&
            (uintptr_t)f.rstats % 8 == 0;
@@ -778,7 +950,9 @@ void launch_mfma_bf16_dense_w4(void *out, const void *x, const void *w, const vo
   switch (act) {
     case GNLP_ACT_RELU: launch_w4_other<GNLP_ACT_RELU>(a, width, mode, s); break;
     case GNLP_ACT_GELU_ERF: launch_w4_other<GNLP_ACT_GELU_ERF>(a, width, mode, s); break;
-    case GNLP_ACT_GELU_TANH: launch_w4_other<GNLP_ACT_GELU_TANH>(a, width, mode, s); break;
+    case GNLP_ACT_GELU_TANH:   // (no FOLD 1 instantiation: mfma_bf16_dense_w4_fold_supported)
+      launch_w4_other<GNLP_ACT_GELU_TANH>(a, width, 0, s);
+      break;
     default: launch_w4_other<GNLP_ACT_IDENTITY>(a, width, mode, s); break;
   }
 }

@@ -190,7 +190,7 @@ def test_t5_rel_score_backward(nlp, bidirectional, dtype):
 @pytest.mark.parametrize('M,N,K', [(37, 24, 40), (512, 256, 128)])
 def test_dense_backward(nlp, dtype, M, N, K):
     """Plain Dense under autograd: dx = g W, dW = g^T x, db = column sums (gnlp_dense on transposed
-    operands + gnlp_colsum); fused epilogues refuse to be differentiated."""
+    operands + gnlp_colsum)."""
     from gluonnlp_amd.layers import Dense
     rng = np.random.default_rng(M + N)
     dn = 'float32' if dtype == torch.float32 else 'bfloat16'
@@ -209,7 +209,10 @@ def test_dense_backward(nlp, dtype, M, N, K):
     assert rel_err(to_np(xd.grad), pg @ pw) < t
     assert rel_err(to_np(d.weight.grad), pg.reshape(-1, N).T @ px.reshape(-1, K)) < t
     assert rel_err(to_np(d.bias.grad), pg.reshape(-1, N).sum(0)) < t
-    with pytest.raises(NotImplementedError):
-        d(xd, act='gelu')
+    # fused epilogues record their backward too since round 3 (tests/test_gpu_backward_layers.py);
+    # writing into a caller's buffer cannot be recorded
+    assert d(xd, act='gelu').requires_grad
+    with pytest.raises(ValueError):
+        d(xd, out=torch.empty_like(y))
     with torch.no_grad():
         assert not d(xd, act='gelu').requires_grad
