@@ -318,9 +318,12 @@ def main():
         achieved = kflops / (ms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch of the dominant kernel, from the separate PMC passes
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r02g_hbm_traffic_pmc.json')))
+            # (the instantiation the forward launches: <GELU, no residual, 256 wide, FOLD 1> with
+            # the LayerNorm folded in -- the default -- or <..., FOLD 0> with GNLP_LN_FOLD=0)
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r03_hbm_traffic_pmc.json')))
+            want = '<2, false, 8, 0>' if os.environ.get('GNLP_LN_FOLD') == '0' else '<2, false, 8, 1>'
             for k, v in tj.items():
-                if 'dense_bf16_w4' in k and '<2' in k and args.config == 'bert_large' and act == 'gelu':
+                if 'dense_bf16_w4' in k and want in k and args.config == 'bert_large' and act == 'gelu':
                     traffic = (v['fetch_MB_corrected_x2'] + v['write_MB']) * 1048576.0
         except Exception:
             traffic = None
