@@ -1462,11 +1462,50 @@ size_t gnlp_t5_workspace_bytes(const gnlp_t5_cfg *cfg, int64_t B, int64_t L) {
          align256((size_t)cfg->heads * (2 * L) * sizeof(float));
 }
 
-int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params *layers,
-                            int n_layers, const void *final_ln_g, const void *final_ln_b,
-                            const gnlp_t5_cfg *cfg, int64_t B, int64_t L, const void *valid_length,
-                            int vl_dtype, const void *position_bias, void *workspace,
-                            size_t workspace_bytes, gnlp_stream_t stream) {
+namespace {
+// RMSNorm folded into the GEMMs that consume it (bf16, relu FFN, packed q | k | v weights, rows a
+// multiple of 256): RMSNorm(h) . W^T = r (h . W'^T), W' = bf16(gamma * W),
+// r = rsqrt(mean(h^2) + eps) -- FOLD 1 with r * mu = 0.  The pre-norm residuals are plain tensors:
+// proj and ffn_2 run FOLD 2 with gamma = 1, beta = 0, r = 1 (exactly acc + other) for the sake
+// of its by-product, the partial sums of squares of the output rows, from which the next norm's
+// r comes without a pass over the tensor.
+bool t5_can_fold(const gnlp_t5_cfg *c, int64_t B, int64_t L, const void *ws,
+                 const gnlp_t5_block_params *layers, const gnlp_t5_block_folded *folded,
+                 int n_layers) {
+  const int64_t M = B * L, D = c->d_model, inner = c->heads * c->d_kv, F = c->d_ff;
+  if (!folded || !knobs().ln_fold || c->dtype != GNLP_BF16 || c->gated || M % 256 != 0 ||
+      D > 2048 || !row_stats_supported(D, ws))
+    return false;
+  for (int i = 0; i < n_layers; ++i) {
+    const gnlp_t5_block_params *p = &layers[i];
+    const gnlp_t5_block_folded *f = &folded[i];
+    if (!p->qkv_w || !f->qkv_wf || !f->qkv_c || !f->qkv_bf || !f->ffn1_wf || !f->ffn1_c ||
+        !f->ffn1_bf || p->ffn.gate_w || p->ffn.ffn1_b || p->ffn.ffn2_b)
+      return false;
+    if (((uintptr_t)f->qkv_wf | (uintptr_t)f->qkv_c | (uintptr_t)f->qkv_bf | (uintptr_t)f->ffn1_wf |
+         (uintptr_t)f->ffn1_c | (uintptr_t)f->ffn1_bf) % 16)
+      return false;
+    if (!mfma_bf16_dense_takes_w4(M, 3 * inner, D, D, 3 * inner, 0, ws, nullptr, nullptr) ||
+        !mfma_bf16_dense_takes_w4(M, D, inner, inner, D, D, ws, nullptr, ws) ||
+        !mfma_bf16_dense_takes_w4(M, F, D, D, F, 0, ws, nullptr, nullptr) ||
+        !mfma_bf16_dense_takes_w4(M, D, F, F, D, D, ws, nullptr, ws))
+      return false;
+  }
+  DenseFold f1{1, (const float *)ws, (const float *)ws, (const float *)ws, nullptr, nullptr, nullptr};
+  DenseFold f2{2, (const float *)ws, nullptr, nullptr, ws, ws, (float *)ws};
+  return mfma_bf16_dense_w4_fold_supported(f1, GNLP_ACT_IDENTITY, 0, nullptr, 3 * inner) &&
+         mfma_bf16_dense_w4_fold_supported(f1, GNLP_ACT_RELU, 0, nullptr, F) &&
+         mfma_bf16_dense_w4_fold_supported(f2, GNLP_ACT_IDENTITY, GNLP_COMBINE_ADD, ws, D);
+}
+}  // namespace
+
+static int t5_encoder_impl(void *out, const void *x, const gnlp_t5_block_params *layers,
+                           const gnlp_t5_block_folded *folded, int n_layers,
+                           const void *final_ln_g, const void *final_ln_b, const gnlp_t5_cfg *cfg,
+                           int64_t B, int64_t L, const void *valid_length, int vl_dtype,
+                           const void *position_bias, void *workspace, size_t workspace_bytes,
+                           gnlp_stream_t stream) {
+  g_stack_folded = 0;
   REQUIRE(cfg && layers && n_layers >= 1, "NULL cfg / layers");
   REQUIRE(dtype_ok(cfg->dtype), "unsupported dtype %d", cfg->dtype);
   REQUIRE(cfg->d_model > 0 && cfg->d_kv > 0 && cfg->d_ff > 0 && cfg->heads > 0, "bad T5 sizes");
@@ -1500,18 +1539,43 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
     launch_widen_bf16(tab, position_bias, H * (2 * L - 1), s);
     bias_f32 = tab + (L - 1);
   }
+  // folded path: constants and statistics live where the plain path keeps the normalised tensor
+  const bool fold = t5_can_fold(cfg, B, L, base, layers, folded, n_layers);
+  float *rs_a = nullptr, *rs_b = nullptr, *rs_one = nullptr, *part = nullptr;
+  void *ones = nullptr, *zeros = nullptr;
+  if (fold) {
+    const size_t rs_bytes = align256((size_t)M * 2 * sizeof(float));
+    const size_t part_bytes = fold_part_bytes(M, D), vec_bytes = align256((size_t)D * e);
+    if (3 * rs_bytes + part_bytes + 2 * vec_bytes <= align256((size_t)M * D * e)) {
+      char *q = base + w.normed;
+      rs_a = (float *)q; rs_b = (float *)(q + rs_bytes); rs_one = (float *)(q + 2 * rs_bytes);
+      part = (float *)(q + 3 * rs_bytes);
+      ones = q + 3 * rs_bytes + part_bytes; zeros = (char *)ones + vec_bytes;
+      launch_fold_consts(ones, zeros, rs_one, D, M, s);
+      launch_row_stats(rs_a, x, cfg->ln_eps, M, D, s, true);   // t5.py:537 of the first block
+      g_stack_folded = 1;
+    }
+  }
   for (int i = 0; i < n_layers; ++i) {
     const gnlp_t5_block_params *p = &layers[i];
     REQUIRE(p->attn_ln_g && (p->qkv_w || (p->q_w && p->k_w && p->v_w)) && p->proj_w && p->ffn.ffn1_w &&
             p->ffn.ffn2_w && p->ffn.ln_g, "missing weights in T5 block %d", i);
     const bool last = (i == n_layers - 1);
     void *dst = (last && !final_ln_g) ? out : pp[i & 1];
+    char *qkv = base + w.qkv;
+    if (rs_a) {   // q | k | v = r (h . W'^T) [+ b']
+      const DenseFold fd{1, rs_a, folded[i].qkv_c, folded[i].qkv_bf, nullptr, nullptr, nullptr};
+      rc = dense_impl(qkv, h, folded[i].qkv_wf, nullptr, nullptr, 0, GNLP_ACT_IDENTITY, cfg->dtype,
+                      M, 3 * inner, D, D, 3 * inner, 0, s, &fd);
+      if (rc) return rc;
+    } else {
     // t5.py:537  out = self_attn_layer_norm(hidden)
     launch_norm(base + w.normed, h, nullptr, p->attn_ln_g, p->attn_ln_b, cfg->dtype, GNLP_NORM_RMS,
                 cfg->ln_eps, M, D, nullptr, 0, 0, 0, 0, s);
+    }
     // t5.py:538-542  bias-free q / k / v projections written side by side: [q | k | v] rows
-    char *qkv = base + w.qkv;
-    if (p->qkv_w) {   // the three weights packed row-wise: one GEMM of N = 3 * inner
+    if (rs_a) {
+    } else if (p->qkv_w) {   // the three weights packed row-wise: one GEMM of N = 3 * inner
       rc = dense_impl(qkv, base + w.normed, p->qkv_w, nullptr, nullptr, 0, GNLP_ACT_IDENTITY,
                       cfg->dtype, M, 3 * inner, D, D, 3 * inner, 0, s);
       if (rc) return rc;
@@ -1546,6 +1610,26 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
                    vl_dtype, bias0, bias0 ? estr : nullptr, 0.0f, base + w.ffn,
                    w.total - w.ffn, s, nullptr, bias_f32);
     if (rc) return rc;
+    if (rs_a) {
+      // t5.py:550-551  hidden = hidden + proj(out), leaving the partial sums of squares of its rows
+      const DenseFold f2{2, rs_one, nullptr, nullptr, ones, zeros, part};
+      rc = dense_impl(base + w.h1, base + w.ctx, p->proj_w, nullptr, h, GNLP_COMBINE_ADD,
+                      GNLP_ACT_IDENTITY, cfg->dtype, M, D, inner, inner, D, D, s, &f2);
+      if (rc) return rc;
+      launch_stats_finish(rs_b, part, fold_stat_slots(M, D), f.ln_eps, M, D, s, true);
+      // t5.py:571  ffn: hidden + ffn_2(relu(ffn_1(RMSNorm(hidden))))
+      void *hid = base + w.ffn;
+      const DenseFold f1{1, rs_b, folded[i].ffn1_c, folded[i].ffn1_bf, nullptr, nullptr, nullptr};
+      rc = dense_impl(hid, base + w.h1, folded[i].ffn1_wf, nullptr, nullptr, 0, f.act, cfg->dtype, M,
+                      cfg->d_ff, D, D, cfg->d_ff, 0, s, &f1);
+      if (rc) return rc;
+      rc = dense_impl(dst, hid, p->ffn.ffn2_w, nullptr, base + w.h1, GNLP_COMBINE_ADD,
+                      GNLP_ACT_IDENTITY, cfg->dtype, M, D, cfg->d_ff, cfg->d_ff, D, D, s, &f2);
+      if (rc) return rc;
+      if (!last) launch_stats_finish(rs_a, part, fold_stat_slots(M, D), cfg->ln_eps, M, D, s, true);
+      h = dst;
+      continue;
+    }
     // t5.py:550-551  hidden = hidden + proj(out)
     rc = dense_impl(base + w.h1, base + w.ctx, p->proj_w, nullptr, h, GNLP_COMBINE_ADD,
                     GNLP_ACT_IDENTITY, cfg->dtype, M, D, inner, inner, D, D, s);
@@ -1561,6 +1645,26 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
                 D, nullptr, 0, 0, 0, 0, s);
   }
   return check_launch("gnlp_t5_encoder_forward");
+}
+
+int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params *layers,
+                            int n_layers, const void *final_ln_g, const void *final_ln_b,
+                            const gnlp_t5_cfg *cfg, int64_t B, int64_t L, const void *valid_length,
+                            int vl_dtype, const void *position_bias, void *workspace,
+                            size_t workspace_bytes, gnlp_stream_t stream) {
+  return t5_encoder_impl(out, x, layers, nullptr, n_layers, final_ln_g, final_ln_b, cfg, B, L,
+                         valid_length, vl_dtype, position_bias, workspace, workspace_bytes, stream);
+}
+
+int gnlp_t5_encoder_forward_folded(void *out, const void *x, const gnlp_t5_block_params *layers,
+                                   const gnlp_t5_block_folded *folded, int n_layers,
+                                   const void *final_ln_g, const void *final_ln_b,
+                                   const gnlp_t5_cfg *cfg, int64_t B, int64_t L,
+                                   const void *valid_length, int vl_dtype,
+                                   const void *position_bias, void *workspace,
+                                   size_t workspace_bytes, gnlp_stream_t stream) {
+  return t5_encoder_impl(out, x, layers, folded, n_layers, final_ln_g, final_ln_b, cfg, B, L,
+                         valid_length, vl_dtype, position_bias, workspace, workspace_bytes, stream);
 }
 
 /* ---- measurement hook (see include/gluonnlp_amd.h) ---- */

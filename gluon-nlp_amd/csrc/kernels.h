@@ -112,9 +112,11 @@ void launch_norm(void *out, const void *x, const void *residual, const void *gam
 // and the folded parameters (wf, c, bf) of the Dense that consumes the norm (see DenseFold)
 bool row_stats_supported(int64_t C, const void *x);
 void launch_row_stats(float *rstats, const void *x, float eps, int64_t rows, int64_t C,
-                      hipStream_t s);
+                      hipStream_t s, bool rms = false);
 void launch_stats_finish(float *rstats, const float *part, int64_t slots, float eps, int64_t rows,
-                         int64_t C, hipStream_t s);
+                         int64_t C, hipStream_t s, bool rms = false);
+void launch_fold_consts(void *ones, void *zeros, float *rs_one, int64_t C, int64_t rows,
+                        hipStream_t s);
 void launch_fold_norm_dense(void *wf, float *c, float *bfold, const void *w, const void *b,
                             const void *gamma, const void *beta, int64_t N, int64_t K,
                             int64_t n_scaled, float scale, hipStream_t s);

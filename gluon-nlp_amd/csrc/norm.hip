@@ -207,7 +207,7 @@ void launch_norm(void *out, const void *x, const void *residual, const void *gam
 template <int MAXV>
 __global__ void __launch_bounds__(256)
 row_stats_kernel(float *__restrict__ rstats, const bf16 *__restrict__ x, float eps, int64_t rows,
-                 int C, const int32_t *__restrict__ rows_dev) {
+                 int C, const int32_t *__restrict__ rows_dev, int rms) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -231,7 +231,8 @@ row_stats_kernel(float *__restrict__ rstats, const bf16 *__restrict__ x, float e
       for (int q = 0; q < 8; ++q) vals[i][q] = 0.0f;
     }
   }
-  const float mean = wave_sum(sum) / (float)C;
+  // (rms: RMSNorm has no mean term -- r = rsqrt(mean(x^2) + eps), r * mean := 0)
+  const float mean = rms ? 0.0f : wave_sum(sum) / (float)C;
   float ss = 0.0f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -252,7 +253,8 @@ row_stats_kernel(float *__restrict__ rstats, const bf16 *__restrict__ x, float e
 // var = E[x^2] - mean^2 in fp32 (relative error ~1e-7 E[x^2] / var: 1e-5 at |mean| = 10 sigma).
 __global__ void __launch_bounds__(256)
 stats_finish_kernel(float *__restrict__ rstats, const float *__restrict__ part, int slots,
-                    float eps, int64_t rows, float inv_c, const int32_t *__restrict__ rows_dev) {
+                    float eps, int64_t rows, float inv_c, const int32_t *__restrict__ rows_dev,
+                    int rms) {
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   if (rows_dev && row >= *rows_dev) return;
@@ -263,17 +265,34 @@ stats_finish_kernel(float *__restrict__ rstats, const float *__restrict__ part, 
     s += v[0];
     q += v[1];
   }
-  const float mean = s * inv_c;
+  const float mean = rms ? 0.0f : s * inv_c;
   const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
   const float rstd = 1.0f / sqrtf(var + eps);
   *reinterpret_cast<f32x2 *>(rstats + row * 2) = (f32x2){rstd, rstd * mean};
 }
 
 void launch_stats_finish(float *rstats, const float *part, int64_t slots, float eps, int64_t rows,
-                         int64_t C, hipStream_t s) {
+                         int64_t C, hipStream_t s, bool rms) {
   if (rows == 0) return;
   stats_finish_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(
-      rstats, part, (int)slots, eps, rows, 1.0f / (float)C, dense_rows_dev());
+      rstats, part, (int)slots, eps, rows, 1.0f / (float)C, dense_rows_dev(), rms ? 1 : 0);
+}
+
+// Constants of a folded pre-norm (RMSNorm) stack: its residuals are plain tensors, which the FOLD 2
+// drain adds exactly when told gamma = 1, beta = 0, r = 1, r * mu = 0 (acc + 1 * (1 * o - 0)).
+__global__ void __launch_bounds__(256)
+fold_consts_kernel(bf16 *__restrict__ ones, bf16 *__restrict__ zeros, float *__restrict__ rs_one,
+                   int64_t C, int64_t rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < C) { ones[i] = (bf16)1.0f; zeros[i] = (bf16)0.0f; }
+  if (i < rows) *reinterpret_cast<f32x2 *>(rs_one + i * 2) = (f32x2){1.0f, 0.0f};
+}
+void launch_fold_consts(void *ones, void *zeros, float *rs_one, int64_t C, int64_t rows,
+                        hipStream_t s) {
+  const int64_t n = C > rows ? C : rows;
+  if (n == 0) return;
+  fold_consts_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((bf16 *)ones, (bf16 *)zeros, rs_one,
+                                                                 C, rows);
 }
 
 bool row_stats_supported(int64_t C, const void *x) {
@@ -281,15 +300,15 @@ bool row_stats_supported(int64_t C, const void *x) {
 }
 
 void launch_row_stats(float *rstats, const void *x, float eps, int64_t rows, int64_t C,
-                      hipStream_t s) {
+                      hipStream_t s, bool rms) {
   if (rows == 0) return;
   dim3 grid((unsigned)((rows + 3) / 4));
   if (C <= 1024)
     row_stats_kernel<2><<<grid, 256, 0, s>>>(rstats, (const bf16 *)x, eps, rows, (int)C,
-                                             dense_rows_dev());
+                                             dense_rows_dev(), rms ? 1 : 0);
   else
     row_stats_kernel<4><<<grid, 256, 0, s>>>(rstats, (const bf16 *)x, eps, rows, (int)C,
-                                             dense_rows_dev());
+                                             dense_rows_dev(), rms ? 1 : 0);
 }
 
 // The folded parameters of a Dense that consumes LayerNorm(s) (run once per parameter version):

@@ -70,6 +70,11 @@ class T5BlockParams(Structure):
                 ('qkv_w', c_void_p)]
 
 
+class T5BlockFolded(Structure):
+    _fields_ = [('qkv_wf', c_void_p), ('qkv_c', c_void_p), ('qkv_bf', c_void_p),
+                ('ffn1_wf', c_void_p), ('ffn1_c', c_void_p), ('ffn1_bf', c_void_p)]
+
+
 class T5Cfg(Structure):
     _fields_ = [('d_model', c_int64), ('d_kv', c_int64), ('d_ff', c_int64), ('heads', c_int64),
                 ('gated', c_int), ('dtype', c_int), ('time_major', c_int), ('ln_eps', c_float),
@@ -185,6 +190,10 @@ PROTOTYPES = {
     'gnlp_t5_encoder_forward': (c_int, [c_void_p, c_void_p, POINTER(T5BlockParams), c_int,
                                         c_void_p, c_void_p, POINTER(T5Cfg), c_int64, c_int64,
                                         c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'gnlp_t5_encoder_forward_folded': (c_int, [c_void_p, c_void_p, POINTER(T5BlockParams),
+                                               POINTER(T5BlockFolded), c_int, c_void_p, c_void_p,
+                                               POINTER(T5Cfg), c_int64, c_int64, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

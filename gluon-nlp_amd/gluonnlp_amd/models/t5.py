@@ -217,6 +217,63 @@ class T5Block(nn.Module):
         return self.ffn(hidden_states)
 
 
+# ---- RMSNorms folded into the GEMMs that consume them (bf16 encoder blocks with a relu FFN) -------
+# gnlp_t5_encoder_forward_folded takes, per block, W' = bf16(gamma * W) (+ c, b') of the packed
+# q | k | v weights (with the block's self_attn_layer_norm) and of ffn.ffn_1 (with ffn.layer_norm):
+# functions of the parameters only, computed on the device once per parameter version and kept with
+# the first block.  Key and limit as for the encoder stacks (models/transformer.py): an in-place
+# write through ``.data`` is not seen -- drop_folded_parameters(model) after such an edit.
+_T5_FOLD_ATTR = '_gnlp_folded_params'   # (the attribute drop_folded_parameters deletes)
+
+
+def _t5_fold_sources(blocks):
+    for b in blocks:
+        yield b.packed_qkv()
+        for t in (b.self_attn_layer_norm.gamma, getattr(b.self_attn_layer_norm, 'beta', None),
+                  b.ffn.ffn_1.weight, b.ffn.layer_norm.gamma,
+                  getattr(b.ffn.layer_norm, 'beta', None)):
+            yield t
+
+
+def _t5_folded_params(blocks, dev):
+    """(ctypes array, tensors kept alive), or None when the blocks cannot fold at all."""
+    b0 = blocks[0]
+    if not _PACK_QKV or b0.self_attn_q.weight.dtype != torch.bfloat16:
+        return None
+    for b in blocks:
+        if b._is_decoder or b._activation != 'relu' or b.ffn.ffn_1.bias is not None:
+            return None
+    src = list(_t5_fold_sources(blocks))
+    key = tuple(None if t is None else (t.data_ptr(), t._version) for t in src)
+    cached = getattr(b0, _T5_FOLD_ATTR, None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    lib = _lib.load()
+    stream = T.stream(dev)
+    keep = []
+    arr = (_lib.T5BlockFolded * len(blocks))()
+
+    def fold(w, norm):
+        w = w.data.contiguous()
+        N, K = w.shape
+        wf = torch.empty_like(w)
+        c = torch.empty(N, dtype=torch.float32, device=dev)
+        bf = torch.empty(N, dtype=torch.float32, device=dev)
+        beta = getattr(norm, 'beta', None)
+        _lib.check(lib.gnlp_fold_norm_dense(
+            T.ptr(wf), T.ptr(c), T.ptr(bf), T.ptr(w), None, T.ptr(norm.gamma.data),
+            T.ptr(beta.data) if beta is not None else None, _lib.BF16, N, K, 0, 1.0, stream))
+        keep.extend([wf, c, bf, w])
+        return T.ptr(wf), T.ptr(c), T.ptr(bf)
+
+    for i, b in enumerate(blocks):
+        arr[i].qkv_wf, arr[i].qkv_c, arr[i].qkv_bf = fold(b.packed_qkv(), b.self_attn_layer_norm)
+        arr[i].ffn1_wf, arr[i].ffn1_c, arr[i].ffn1_bf = fold(b.ffn.ffn_1.weight, b.ffn.layer_norm)
+    keep.extend(t.data for t in src if t is not None)
+    object.__setattr__(b0, _T5_FOLD_ATTR, (key, arr, keep))
+    return arr, keep
+
+
 def run_t5_blocks(blocks, hidden_states, valid_length, position_bias, final_ln, layout,
                   toeplitz=False):
     """All blocks (+ the final RMSNorm) in ONE C call (gnlp_t5_encoder_forward).  ``toeplitz``:
@@ -251,12 +308,18 @@ def run_t5_blocks(blocks, hidden_states, valid_length, position_bias, final_ln, 
     lib = _lib.load()
     ws = T.workspace(dev, lib.gnlp_t5_workspace_bytes(ctypes.byref(cfg), B, L))
     out = torch.empty_like(x)
-    _lib.check(lib.gnlp_t5_encoder_forward(
-        T.ptr(out), T.ptr(x), arr, n,
-        T.ptr(final_ln.gamma.data) if final_ln is not None else None,
-        T.ptr(final_ln.beta.data) if final_ln is not None else None,
-        ctypes.byref(cfg), B, L, vlp, vlc, T.ptr(pb), T.ptr(ws),
-        0 if ws is None else ws.numel(), T.stream(dev)))
+    fin_g = T.ptr(final_ln.gamma.data) if final_ln is not None else None
+    fin_b = T.ptr(final_ln.beta.data) if final_ln is not None and \
+        getattr(final_ln, 'beta', None) is not None else None
+    folded = _t5_folded_params(blocks, dev) if (B * L) % 256 == 0 else None
+    if folded is not None:
+        _lib.check(lib.gnlp_t5_encoder_forward_folded(
+            T.ptr(out), T.ptr(x), arr, folded[0], n, fin_g, fin_b, ctypes.byref(cfg), B, L, vlp,
+            vlc, T.ptr(pb), T.ptr(ws), 0 if ws is None else ws.numel(), T.stream(dev)))
+    else:
+        _lib.check(lib.gnlp_t5_encoder_forward(
+            T.ptr(out), T.ptr(x), arr, n, fin_g, fin_b, ctypes.byref(cfg), B, L, vlp, vlc, T.ptr(pb),
+            T.ptr(ws), 0 if ws is None else ws.numel(), T.stream(dev)))
     return T.like_caller(out, hidden_states)
 
 

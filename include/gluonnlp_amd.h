@@ -537,6 +537,32 @@ int gnlp_t5_encoder_forward(void *out, const void *x, const gnlp_t5_block_params
                             const void *position_bias, void *workspace, size_t workspace_bytes,
                             gnlp_stream_t stream);
 
+/* The same forward with every RMSNorm folded into the GEMM that consumes it (round 3; no
+ * counterpart in the reference, whose blocks run RMSNorm as an operator of its own,
+ * models/t5.py:537,571, layers.py:634-635 -- the same arithmetic regrouped):
+ *     RMSNorm(h) . W^T = r (h . W'^T) + b',   W' = bf16(gamma * W),  b' = beta . W^T,
+ *     r = rsqrt(mean(h^2) + eps)
+ * (gnlp_fold_norm_dense builds W', c, b'; c goes unused: there is no mean term).  The packed
+ * q | k | v weights are folded with the block's self_attn_layer_norm, ffn_1 with the FFN's
+ * layer_norm.  The residual GEMMs (proj, ffn_2) leave partial sums of squares of their output rows,
+ * from which the next norm's r comes without a pass over the tensor.  Conditions: bf16, relu FFN
+ * (not gated), qkv_w packed, B * L a multiple of 256, d_model <= 2048, all four GEMM shapes taken
+ * by the persistent kernel; otherwise -- and with GNLP_LN_FOLD=0 -- exactly
+ * gnlp_t5_encoder_forward runs.  gnlp_stack_last_folded() tells which. */
+typedef struct {
+  const void *qkv_wf;              /* (3 inner, d_model) bf16 */
+  const float *qkv_c, *qkv_bf;     /* (3 inner) fp32 x 2 */
+  const void *ffn1_wf;             /* (d_ff, d_model) bf16 */
+  const float *ffn1_c, *ffn1_bf;   /* (d_ff) fp32 x 2 */
+} gnlp_t5_block_folded;
+int gnlp_t5_encoder_forward_folded(void *out, const void *x, const gnlp_t5_block_params *layers,
+                                   const gnlp_t5_block_folded *folded, int n_layers,
+                                   const void *final_ln_g, const void *final_ln_b,
+                                   const gnlp_t5_cfg *cfg, int64_t B, int64_t L,
+                                   const void *valid_length, int vl_dtype,
+                                   const void *position_bias, void *workspace,
+                                   size_t workspace_bytes, gnlp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference; for bench.py's roofline object).  While
  * armed, every dense launch of exactly this (M, N, K) -- from gnlp_dense or from inside the block

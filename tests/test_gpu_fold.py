@@ -259,3 +259,78 @@ def test_folded_parameters_follow_the_parameters(nlp, tiles256):
     x2 = to_dev(rng.standard_normal((3, 100, U)), torch.bfloat16)
     m(x2, torch.tensor([100, 3, 50], device='cuda'))
     assert _lib.load().gnlp_stack_last_folded() == 0
+
+
+# ---- T5: RMSNorm folded into the GEMMs that consume it (gnlp_t5_encoder_forward_folded) -----------
+def _t5(D, DKV, DFF, H, NL, rng, beta=False):
+    from gluonnlp_amd.models import T5Encoder
+    lps = [ref.make_t5_block_params(rng, D, DKV, DFF, H, False) for _ in range(NL)]
+    if beta:   # (the reference's RMSNorm carries a beta too: b' = beta . W^T of the fold)
+        for lp in lps:
+            lp['self_attn_layer_norm.beta'] = (0.1 * rng.standard_normal(D)).astype(np.float32)
+            lp['ffn.layer_norm.beta'] = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    relw = (rng.standard_normal((32, H)) * D ** -0.5).astype(np.float32)
+    fin = {'gamma': (1 + 0.1 * rng.standard_normal(D)).astype(np.float32),
+           'beta': np.zeros(D, np.float32)}
+    enc = T5Encoder(D, DKV, DFF, num_layers=NL, num_heads=H, activation='relu', dtype='bfloat16')
+    for i in range(NL):
+        load_params(enc.layers[i], lps[i], torch.bfloat16)
+    load_params(enc.final_layer_norm, fin, torch.bfloat16)
+    load_params(enc.relative_position_encoder, {'_rel_pos_embed.weight': relw}, torch.bfloat16)
+    return enc.cuda(), lps, relw, fin
+
+
+@pytest.mark.parametrize('D,DKV,DFF,H,NL,B,L,beta', [(256, 64, 1024, 4, 2, 2, 128, False),
+                                                    (768, 64, 3072, 12, 3, 2, 256, True)])
+def test_folded_t5_encoder_against_oracle_and_plain(nlp, tiles256, D, DKV, DFF, H, NL, B, L, beta):
+    """T5Encoder (pre-norm RMSNorm blocks, relu FFN, relative-position bias, ragged lengths) with
+    the norms folded: against the float64 oracle at the stack tolerance and against the plain run
+    (GNLP_LN_FOLD=0); 192-wide GEMM tiles at d_model = 768."""
+    rng = np.random.default_rng(D + L)
+    enc, lps, relw, fin = _t5(D, DKV, DFF, H, NL, rng, beta)
+    x = rng.standard_normal((B, L, D))
+    vl = np.array([L, L // 3])
+    xd, vd = to_dev(x, torch.bfloat16), torch.tensor(vl, device='cuda')
+    got = enc(xd, vd)
+    assert _lib.load().gnlp_stack_last_folded() == 1
+    try:
+        _lib.set_knob('GNLP_LN_FOLD', '0')
+        plain = enc(xd, vd)
+        assert _lib.load().gnlp_stack_last_folded() == 0
+    finally:
+        _lib.set_knob('GNLP_LN_FOLD', None)
+    o = lambda a: prep(a, torch.bfloat16)
+    want = ref.t5_encoder(o(x), vl, o(relw), [{k: o(v) for k, v in p.items()} for p in lps],
+                          {k: o(v) for k, v in fin.items()}, H, activation_name='relu')
+    worst = [0.0, 0.0]
+    for b in range(B):
+        n = vl[b]
+        worst[0] = max(worst[0], float(rel_err(to_np(got)[b, :n], want[b, :n])))
+        worst[1] = max(worst[1], float(rel_err(to_np(plain)[b, :n], want[b, :n])))
+    print('[fold] T5 D=%d: folded %.3e, plain %.3e against the oracle' % (D, worst[0], worst[1]))
+    assert worst[0] < np.sqrt(NL + 1) * 2e-2
+    assert worst[0] < worst[1] + 5e-3
+
+
+def test_folded_t5_parameters_follow_updates(nlp, tiles256):
+    """The folded tensors are rebuilt when a source parameter changes version (copy_), kept
+    otherwise; drop_folded_parameters forgets them."""
+    from gluonnlp_amd.models.transformer import drop_folded_parameters
+    rng = np.random.default_rng(4)
+    enc, _, _, _ = _t5(256, 64, 1024, 4, 1, rng)
+    xd = to_dev(rng.standard_normal((2, 128, 256)), torch.bfloat16)
+    vd = torch.tensor([128, 128], device='cuda')
+    a = enc(xd, vd)
+    assert torch.equal(a, enc(xd, vd))
+    with torch.no_grad():
+        enc.layers[0].ffn.layer_norm.gamma.copy_(enc.layers[0].ffn.layer_norm.gamma * 1.5)
+    b = enc(xd, vd)
+    assert not torch.equal(a, b)
+    try:
+        _lib.set_knob('GNLP_LN_FOLD', '0')
+        plain = enc(xd, vd)
+    finally:
+        _lib.set_knob('GNLP_LN_FOLD', None)
+    assert rel_err(to_np(b), to_np(plain)) < 2e-2
+    drop_folded_parameters(enc)
+    assert torch.equal(b, enc(xd, vd))

@@ -189,10 +189,12 @@ def test_cfg4_t5_base_full_size(nlp):
         prev = got_i
     print('[fullsize] t5_base bf16 L=1024 B=16: worst per-block err {:.3e} at block {} (tol {:.0e})'
           .format(worst_block, worst_at, tol(dtype)))
-    # the chain of single-block calls is the stack without its final norm: same kernels, same bits
+    # the chain of single-block calls is the stack without its final norm, on the same kernels; not
+    # bit for bit since the RMSNorm fold (a block called alone takes its input's statistics from a
+    # pass over the tensor, inside the stack they come from the producing GEMM's partial sums)
     fin_d = enc.final_layer_norm(prev_d)
     keep_all = torch.arange(L, device='cuda')[None, :] < vld[:, None]
-    assert torch.equal(fin_d[keep_all], out[keep_all])
+    assert rel_err(to_np(fin_d[keep_all]), to_np(out[keep_all])) < tol(dtype) * NL ** 0.5   # (12 blocks of roundings apart)
     want = ref.t5_encoder(o(x[pick]), vl[pick], o(relw),
                           [{k: o(v) for k, v in p.items()} for p in lps],
                           {k: o(v) for k, v in fin.items()}, H, activation_name='relu')
