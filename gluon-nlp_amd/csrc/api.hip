@@ -588,7 +588,14 @@ bool stack_can_fold(const gnlp_encoder_cfg *c, int64_t B, int64_t L, const void 
         !mfma_bf16_dense_takes_w4(M, U, F, F, U, U, ws, p->ffn.ffn2_b, ws))
       return false;
   }
-  return true;
+  // what the folded instantiations of the persistent kernel take (e.g. no FOLD 1 with the tanh
+  // GELU, N <= 4096 with an activation): asked with stand-in pointers of the right alignment
+  const DenseFold f1{1, (const float *)ws, (const float *)ws, (const float *)ws, nullptr, nullptr,
+                     nullptr};
+  const DenseFold f2{2, (const float *)ws, nullptr, nullptr, ws, ws, (float *)ws};
+  return mfma_bf16_dense_w4_fold_supported(f1, GNLP_ACT_IDENTITY, 0, nullptr, 3 * U) &&
+         mfma_bf16_dense_w4_fold_supported(f1, c->act, 0, nullptr, F) &&
+         mfma_bf16_dense_w4_fold_supported(f2, GNLP_ACT_IDENTITY, GNLP_COMBINE_ADD, ws, U);
 }
 
 // One post-norm layer of a folded stack (models/transformer.py:259-271, layers.py:640-646, the same

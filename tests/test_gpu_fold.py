@@ -334,3 +334,25 @@ def test_folded_t5_parameters_follow_updates(nlp, tiles256):
     assert rel_err(to_np(b), to_np(plain)) < 2e-2
     drop_folded_parameters(enc)
     assert torch.equal(b, enc(xd, vd))
+
+
+def test_stack_with_tanh_gelu_runs_unfolded(nlp, tiles256):
+    """Found by tests/dev_stack_fuzz.py (seed 31, case 89): the persistent kernel has no FOLD 1
+    instantiation for the tanh GELU, and the stack driver used to promise the fold anyway (a loud
+    "unsupported Dense shape").  Such a stack now runs the plain path."""
+    from gluonnlp_amd.models import TransformerEncoder
+    rng = np.random.default_rng(89)
+    B, L, U, F, H = 1, 256, 256, 512, 8
+    lp = [ref.make_encoder_layer_params(rng, U, F)]
+    m = TransformerEncoder(num_layers=1, units=U, hidden_size=F, num_heads=H, pre_norm=False,
+                           layer_norm_eps=1e-12, activation='gelu(tanh)', dtype='bfloat16')
+    load_params(m.layers[0], lp[0], torch.bfloat16)
+    m.cuda()
+    x = rng.standard_normal((B, L, U))
+    vl = np.array([200])
+    got = m(to_dev(x, torch.bfloat16), torch.tensor(vl, device='cuda'))
+    assert _lib.load().gnlp_stack_last_folded() == 0
+    exp = ref.transformer_encoder(prep(x, torch.bfloat16), vl,
+                                  [oracle_params(lp[0], torch.bfloat16)], H, 1e-12, False,
+                                  'gelu(tanh)', 'NT')
+    assert rel_err(to_np(got)[0, :200], exp[0, :200]) < 2e-2
