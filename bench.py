@@ -352,9 +352,11 @@ def main():
             'path_tflops_useful': seqs * useful_fps / 1e12,
             'path_frac_of_mfma_peak_useful': seqs * useful_fps / 1e12 / (peak * world),
             'roofline': {'bound': 'mfma',
-                         'kernel': '{} (FFN-1 GEMM + bias + {}), M={} N={} K={}'.format(
+                         'kernel': '{} (FFN-1 GEMM + bias + {}{}), M={} N={} K={}'.format(
                              'dense_bf16_w4_kernel' if args.dtype == 'bf16' else 'dense_f32_kernel',
-                             act, M, F, U),
+                             act, ', LayerNorm folded in' if (args.dtype == 'bf16' and kind != 't5' and
+                                                              os.environ.get('GNLP_LN_FOLD') != '0')
+                             else '', M, F, U),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
                          'avg_launch_ms': ms, 'launches_measured': n_meas,
