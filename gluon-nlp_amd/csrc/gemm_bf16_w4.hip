@@ -915,7 +915,7 @@ bool mfma_bf16_dense_w4_fold_supported(const DenseFold &f, int act, int combine,
            (uintptr_t)f.rstats % 8 == 0;
   if (f.mode == 2)   // (N <= 2048: the fp32 bias + beta / gamma images share the 16 KiB bias region)
     return N <= 2048 && other && combine == GNLP_COMBINE_ADD && act == GNLP_ACT_IDENTITY && f.rstats &&
-           f.stats_part && (uintptr_t)f.stats_part % 8 == 0 &&
+           f.stats_part && (uintptr_t)f.stats_part % 16 == 0 &&
            f.ln_g && f.ln_b && ((uintptr_t)f.ln_g | (uintptr_t)f.ln_b) % 16 == 0 &&
            (uintptr_t)f.rstats % 8 == 0;
   return f.mode == 0;

@@ -255,16 +255,31 @@ __global__ void __launch_bounds__(256)
 stats_finish_kernel(float *__restrict__ rstats, const float *__restrict__ part, int slots,
                     float eps, int64_t rows, float inv_c, const int32_t *__restrict__ rows_dev,
                     int rms) {
-  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (row >= rows) return;
-  if (rows_dev && row >= *rows_dev) return;
-  const f32x2 *p = reinterpret_cast<const f32x2 *>(part) + row * slots;
+  // 8 lanes per row, each adding the slots 2 j, 2 j + 1 (+ 16, ...) it loads as one 16-byte piece
+  // (a row's 16 slots are one 128-byte line: coalesced), then the 8 lanes in a fixed order
+  const int lane = threadIdx.x & 63, j = lane & 7;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+  const bool live = row < rows && !(rows_dev && row >= *rows_dev);
   float s = 0.0f, q = 0.0f;
-  for (int i = 0; i < slots; ++i) {
-    const f32x2 v = p[i];
-    s += v[0];
-    q += v[1];
+  if (live) {
+    const float *p = part + row * slots * 2;
+    for (int i = 2 * j; i < slots; i += 16) {
+      if (i + 1 < slots) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i * 2);
+        s += v[0]; q += v[1];
+        s += v[2]; q += v[3];
+      } else {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(p + i * 2);
+        s += v[0]; q += v[1];
+      }
+    }
   }
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {   // (xor butterfly: every lane ends with the same sum)
+    s += __shfl_xor(s, m, 64);
+    q += __shfl_xor(q, m, 64);
+  }
+  if (!live || j != 0) return;
   const float mean = rms ? 0.0f : s * inv_c;
   const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
   const float rstd = 1.0f / sqrtf(var + eps);
@@ -274,7 +289,7 @@ stats_finish_kernel(float *__restrict__ rstats, const float *__restrict__ part, 
 void launch_stats_finish(float *rstats, const float *part, int64_t slots, float eps, int64_t rows,
                          int64_t C, hipStream_t s, bool rms) {
   if (rows == 0) return;
-  stats_finish_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(
+  stats_finish_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, s>>>(
       rstats, part, (int)slots, eps, rows, 1.0f / (float)C, dense_rows_dev(), rms ? 1 : 0);
 }
 
